@@ -1,0 +1,145 @@
+/*
+ * rtr.h -- C ABI of the MI355X point-cloud -> framebuffer projector (librtr_hip.so).
+ *
+ * Drop-in boundary for the hot path of the reference's `ProjectCloud` class
+ * (reference: src/RTRenderer/include/project_cloud.h:11-19).  The reference has no
+ * C ABI / FFI of its own -- its boundary is a C++ class dragging in OpenCV, glm
+ * and libtorch -- so these entry points are what a binding of that class would
+ * need: plain pointers and sizes, no torch / OpenCV / glm types.  The header-
+ * compatible C++ facade (csrc/project_cloud_facade.hpp) and the Python mirror are
+ * thin wrappers over exactly these calls; INTEGRATION.md shows the reference-side
+ * binding.
+ *
+ * Conventions
+ *   - every call returns RTR_OK (0) or a negative rtr_status; rtr_last_error()
+ *     gives the text.  The library never calls exit() (the reference does:
+ *     project_cloud.cu:13-17).
+ *   - one context = one GPU = one host thread at a time (project_cloud.cu is not
+ *     re-entrant either).  Multi-GPU = one process (context) per GPU; the caller
+ *     reduces the exposed device buffers between the phase calls (section 5).
+ *   - all work is enqueued on the context's HIP stream; calls that fill host
+ *     buffers synchronise that stream before returning, others do not.
+ *   - the HIP extension is the only implementation: there is no CPU fallback.
+ */
+#ifndef RTR_H
+#define RTR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTR_ABI_VERSION 1
+#define RTR_EMPTY_DEPTH 0x7F7FFFFFu /* render.cu:166, project_cloud.cu:316: bits of FLT_MAX */
+
+typedef struct rtr_ctx rtr_ctx;
+
+typedef enum {
+    RTR_OK = 0,
+    RTR_ERR_INVALID = -1,   /* bad argument / call order                         */
+    RTR_ERR_HIP = -2,       /* a HIP runtime call failed (text in last_error)    */
+    RTR_ERR_NO_OUTPUT = -3, /* both host outputs NULL (project_cloud.cu:270-273) */
+    RTR_ERR_UNSUPPORTED = -4/* e.g. filter with W % 2^levels != 0 (quirk Q3)     */
+} rtr_status;
+
+/* Compile-time constants of the reference, made run-time parameters. */
+typedef struct {
+    float depth_window;       /* render.cu:106            default 0.02f  */
+    float filter_strength;    /* project_cloud.cu:24      default 1.025f */
+    float gradient_threshold; /* project_cloud.cu:25      default 0.03f  */
+    int32_t levels;           /* project_cloud.cu:23      default 4      */
+} rtr_params;
+
+typedef enum { RTR_SCENE_UNIFORM_BOX = 0, RTR_SCENE_ROOM_SHELL = 1 } rtr_scene;
+
+/* ---- 1. life cycle (ProjectCloud ctor/dtor, project_cloud.cu:189-266) ---------- */
+int rtr_abi_version(void);
+/* device: HIP ordinal of the GPU this context owns. */
+int rtr_create(rtr_ctx **out, int device);
+int rtr_destroy(rtr_ctx *ctx);
+const char *rtr_last_error(const rtr_ctx *ctx); /* ctx may be NULL: error of a failed rtr_create */
+void rtr_default_params(rtr_params *p);
+int rtr_set_params(rtr_ctx *ctx, const rtr_params *p);
+int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the
+ * context's own stream; NULL restores the private stream. */
+int rtr_set_stream(rtr_ctx *ctx, void *hip_stream);
+int rtr_synchronize(rtr_ctx *ctx);
+
+/* ---- 2. the resident cloud (project_cloud.cu:191-206) --------------------------- */
+/* Copies n points from HOST memory and stores them as SoA x[] y[] z[] + packed
+ * colour.  xyz_stride_bytes = 16 for the reference's float4 (x,y,z,1) layout
+ * (Octreegrid.h:162-170), 12 for tight xyz.  rgb_stride_bytes = 4 for uchar4
+ * (c0,c1,c2,255) (Octreegrid.h:172-180), 3 for tight triples; channel order is
+ * preserved end to end (B,G,R in the reference).  Replaces any previous cloud. */
+int rtr_upload_points(rtr_ctx *ctx, const float *xyz, size_t xyz_stride_bytes, const uint8_t *rgb,
+                      size_t rgb_stride_bytes, size_t n);
+/* Synthesises points [first, first+count) of a `total`-point scene directly in
+ * HBM (counter-based generator; bit-identical to the oracle's). */
+int rtr_generate_synthetic(rtr_ctx *ctx, int scene, uint64_t seed, uint64_t first, uint64_t count,
+                           uint64_t total);
+int rtr_num_points(const rtr_ctx *ctx, uint64_t *n);
+/* Copies the resident cloud back as float4 / uchar4 AoS (tests, debugging). */
+int rtr_download_points(rtr_ctx *ctx, float *xyzw, uint8_t *rgba, uint64_t first, uint64_t count);
+
+/* ---- 3. camera (project_cloud.cu:318, project_cloud.h:50-59) -------------------- */
+/* P = K4 * E in fp32, row-major, exactly as the reference composes it with glm:
+ * K row-major 3x3 intrinsics, E row-major 4x4 world->camera, both double. */
+int rtr_compose_projection(const double K[9], const double E[16], float P[16]);
+/* (Re)allocates the frame buffers; cheap no-op when unchanged (project_cloud.cu:275-298). */
+int rtr_set_resolution(rtr_ctx *ctx, int width, int height);
+
+/* ---- 4. whole-frame calls (the reference's public methods) ---------------------- */
+/* computeRGBD (project_cloud.cu:268-312): clear, min-depth pass, accumulate pass,
+ * resolve.  host_img: W*H*3 u8 or NULL; host_depth: W*H float or NULL (empty
+ * pixel = FLT_MAX).  Both NULL -> RTR_ERR_NO_OUTPUT like the reference's -1;
+ * use rtr_render() for device-resident output. */
+int rtr_project(rtr_ctx *ctx, const float P[16], uint8_t *host_img, float *host_depth);
+/* computeFilteredRGBD (project_cloud.cu:394-434): rtr_project + depth-heuristic
+ * prefilter; masked pixels read depth -1 and colour 0; also fills the fp16
+ * {1,5,H,W} device tensor consumed by the U-Net (project_cloud.cu:471). */
+int rtr_project_filtered(rtr_ctx *ctx, const float P[16], uint8_t *host_img, float *host_depth);
+/* Same frame sequences without any host copy or host sync (outputs stay in HBM). */
+int rtr_render(rtr_ctx *ctx, const float P[16], int with_filter);
+
+/* ---- 5. phase calls (multi-GPU sharding: reduce between phases) ----------------- */
+/*   rtr_clear -> rtr_min_depth_pass -> [all-reduce MIN of depth]
+ *   -> rtr_accumulate_pass -> [all-reduce / reduce-scatter SUM of accum]
+ *   -> rtr_resolve -> rtr_filter (optional)                                          */
+int rtr_clear(rtr_ctx *ctx);                           /* render.cu:16-31 + project_cloud.cu:317 */
+int rtr_min_depth_pass(rtr_ctx *ctx, const float P[16]);  /* render.cu:53-83   */
+int rtr_accumulate_pass(rtr_ctx *ctx, const float P[16]); /* render.cu:85-130  */
+int rtr_resolve(rtr_ctx *ctx);                         /* render.cu:132-163 */
+int rtr_filter(rtr_ctx *ctx);                          /* project_cloud.cu:331-392 */
+
+/* ---- 6. device-resident buffers (owned by the context, valid until the next
+ *         rtr_set_resolution / rtr_destroy) ---------------------------------------- */
+typedef enum {
+    RTR_BUF_DEPTH = 0,  /* u32 [H*W]    float bits, RTR_EMPTY_DEPTH when empty (project_cloud.h:34) */
+    RTR_BUF_ACCUM = 1,  /* u32 [H*W*4]  (sum c0, sum c1, sum c2, count)          (project_cloud.h:33) */
+    RTR_BUF_IMAGE = 2,  /* u8  [H*W*3]  interleaved, input channel order         (project_cloud.h:26) */
+    RTR_BUF_TENSOR = 3, /* f16 [5*H*W]  planar {1,5,H,W}                         (project_cloud.h:32) */
+    RTR_BUF_MASK = 4,   /* u8  [H*W]    final keep-mask of the prefilter                              */
+    RTR_BUF_MINMAX = 5  /* u32 [2]      depth min / max bits (project_cloud.h:30-31)                  */
+} rtr_buffer;
+int rtr_device_buffer(rtr_ctx *ctx, int which, void **dev_ptr, size_t *bytes);
+/* Synchronous device->host copy of one buffer (bytes must equal its size). */
+int rtr_download_buffer(rtr_ctx *ctx, int which, void *host, size_t bytes);
+
+/* ---- 7. measurement -------------------------------------------------------------- */
+typedef enum {
+    RTR_K_CLEAR = 0, RTR_K_MIN_DEPTH = 1, RTR_K_ACCUMULATE = 2, RTR_K_RESOLVE = 3, RTR_K_FILTER = 4,
+    RTR_K_COUNT = 5
+} rtr_kernel_id;
+/* When enabled, every phase is bracketed by hipEvents on the context's stream;
+ * rtr_timing_get synchronises and returns the accumulated device time. */
+int rtr_timing_enable(rtr_ctx *ctx, int on);
+int rtr_timing_reset(rtr_ctx *ctx);
+int rtr_timing_get(rtr_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTR_H */

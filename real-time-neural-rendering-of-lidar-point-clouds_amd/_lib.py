@@ -1,0 +1,97 @@
+"""ctypes binding of librtr_hip.so (the C ABI in include/rtr.h).
+
+There is deliberately no fallback: if the HIP extension is missing or no GPU is
+visible the calls fail loudly (RtrError / OSError).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librtr_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+# every symbol include/rtr.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "rtr_abi_version", "rtr_create", "rtr_destroy", "rtr_last_error", "rtr_default_params", "rtr_set_params",
+    "rtr_get_params", "rtr_set_stream", "rtr_synchronize", "rtr_upload_points", "rtr_generate_synthetic",
+    "rtr_num_points", "rtr_download_points", "rtr_compose_projection", "rtr_set_resolution", "rtr_project",
+    "rtr_project_filtered", "rtr_render", "rtr_clear", "rtr_min_depth_pass", "rtr_accumulate_pass", "rtr_resolve",
+    "rtr_filter", "rtr_device_buffer", "rtr_download_buffer", "rtr_timing_enable", "rtr_timing_reset",
+    "rtr_timing_get",
+]
+
+RTR_OK, RTR_ERR_INVALID, RTR_ERR_HIP, RTR_ERR_NO_OUTPUT, RTR_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+BUF_DEPTH, BUF_ACCUM, BUF_IMAGE, BUF_TENSOR, BUF_MASK, BUF_MINMAX = range(6)
+K_CLEAR, K_MIN_DEPTH, K_ACCUMULATE, K_RESOLVE, K_FILTER = range(5)
+KERNEL_NAMES = ["clear", "min_depth", "accumulate", "resolve", "filter"]
+SCENES = {"uniform_box": 0, "room_shell": 1}
+EMPTY_DEPTH = 0x7F7FFFFF
+
+
+class RtrParams(C.Structure):
+    _fields_ = [("depth_window", C.c_float), ("filter_strength", C.c_float),
+                ("gradient_threshold", C.c_float), ("levels", C.c_int32)]
+
+
+class RtrError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("rtr error %d: %s" % (code, text))
+        self.code = code
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 build of the in-tree extension (cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-s"] + (["-B"] if force else [])
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("HIP extension %s is missing: run `python __graft_entry__.py` (build()) first; "
+                      "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u64, sz, i32 = C.c_void_p, C.c_uint64, C.c_size_t, C.c_int
+    L.rtr_abi_version.restype = i32
+    L.rtr_create.argtypes = [C.POINTER(vp), i32]
+    L.rtr_destroy.argtypes = [vp]
+    L.rtr_last_error.argtypes = [vp]
+    L.rtr_last_error.restype = C.c_char_p
+    L.rtr_default_params.argtypes = [C.POINTER(RtrParams)]
+    L.rtr_default_params.restype = None
+    L.rtr_set_params.argtypes = [vp, C.POINTER(RtrParams)]
+    L.rtr_get_params.argtypes = [vp, C.POINTER(RtrParams)]
+    L.rtr_set_stream.argtypes = [vp, vp]
+    L.rtr_synchronize.argtypes = [vp]
+    L.rtr_upload_points.argtypes = [vp, vp, sz, vp, sz, sz]
+    L.rtr_generate_synthetic.argtypes = [vp, i32, u64, u64, u64, u64]
+    L.rtr_num_points.argtypes = [vp, C.POINTER(u64)]
+    L.rtr_download_points.argtypes = [vp, vp, vp, u64, u64]
+    L.rtr_compose_projection.argtypes = [vp, vp, vp]
+    L.rtr_set_resolution.argtypes = [vp, i32, i32]
+    L.rtr_project.argtypes = [vp, vp, vp, vp]
+    L.rtr_project_filtered.argtypes = [vp, vp, vp, vp]
+    L.rtr_render.argtypes = [vp, vp, i32]
+    L.rtr_clear.argtypes = [vp]
+    L.rtr_min_depth_pass.argtypes = [vp, vp]
+    L.rtr_accumulate_pass.argtypes = [vp, vp]
+    L.rtr_resolve.argtypes = [vp]
+    L.rtr_filter.argtypes = [vp]
+    L.rtr_device_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz)]
+    L.rtr_download_buffer.argtypes = [vp, i32, vp, sz]
+    L.rtr_timing_enable.argtypes = [vp, i32]
+    L.rtr_timing_reset.argtypes = [vp]
+    L.rtr_timing_get.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64)]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("rtr_last_error", "rtr_default_params"):
+            fn.restype = i32
+    _lib = L
+    return L

@@ -1,0 +1,554 @@
+// rtr_api.hip -- the C ABI of include/rtr.h on top of the gfx950 kernels.
+//
+// Host orchestration that replaces project_cloud.cu:189-434: the cloud stays
+// resident in HBM as SoA, frame buffers and all pyramid levels are allocated once
+// per resolution (the reference mallocs/frees 12 buffers per filtered frame,
+// project_cloud.cu:346-390), every launch goes to one stream with no device-wide
+// synchronisation in between (the reference calls cudaDeviceSynchronize ten times
+// per frame), and the camera matrix travels as a kernel argument.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtr.h"
+#include "rtr_kernels.h"
+
+struct rtr_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    rtr_params prm{};
+    std::string err;
+
+    // resident cloud (SoA)
+    float *x = nullptr, *y = nullptr, *z = nullptr;
+    uint32_t *rgba = nullptr;
+    uint64_t n = 0, cap = 0;
+
+    // frame buffers
+    int W = 0, H = 0;
+    uint32_t *depth = nullptr, *acc = nullptr, *minmax = nullptr;
+    uint8_t *img = nullptr, *mask = nullptr, *grad = nullptr;
+    uint16_t *tensor = nullptr;
+    rtr::FilterLevels lv{};
+    int lv_levels = 0;  // levels the pyramid was allocated for
+
+    // timing
+    bool timing = false;
+    struct Span { hipEvent_t a, b; int k; };
+    std::vector<Span> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double total_ms[RTR_K_COUNT] = {0};
+    uint64_t launches[RTR_K_COUNT] = {0};
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(rtr_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail((c), RTR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                     \
+    } while (0)
+
+#define NEED(c, cond, msg) \
+    do { if (!(cond)) return fail((c), RTR_ERR_INVALID, "%s", msg); } while (0)
+
+namespace {
+
+struct DevGuard {  // contexts pin their device for the duration of a call
+    explicit DevGuard(int dev) { (void)hipSetDevice(dev); }
+};
+
+template <class T>
+void dfree(T *&p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+void free_frame(rtr_ctx *c) {
+    dfree(c->depth); dfree(c->acc); dfree(c->img); dfree(c->mask); dfree(c->grad); dfree(c->tensor);
+    for (int i = 1; i <= 8; ++i) dfree(c->lv.lv[i]);
+    c->lv.lv[0] = nullptr;
+    c->W = c->H = 0;
+    c->lv_levels = 0;
+}
+
+void free_cloud(rtr_ctx *c) {
+    dfree(c->x); dfree(c->y); dfree(c->z); dfree(c->rgba);
+    c->n = c->cap = 0;
+}
+
+int alloc_cloud(rtr_ctx *c, uint64_t n) {
+    uint64_t n_pad = (n + 3) & ~3ull;
+    if (n_pad == 0) n_pad = 4;
+    if (n_pad > c->cap) {
+        free_cloud(c);
+        HIP_TRY(c, hipMalloc((void **)&c->x, n_pad * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->y, n_pad * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->z, n_pad * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->rgba, n_pad * 4));
+        c->cap = n_pad;
+    }
+    c->n = n;
+    return RTR_OK;
+}
+
+rtr::Proj make_proj(const float P[16]) {
+    rtr::Proj p;
+    for (int i = 0; i < 12; ++i) p.m[i] = P[i];
+    return p;
+}
+
+rtr::Cloud cloud_of(const rtr_ctx *c) { return rtr::Cloud{c->x, c->y, c->z, c->rgba, c->n}; }
+
+struct Timed {  // brackets one phase with hipEvents on the context's stream
+    rtr_ctx *c; int k; hipEvent_t a = nullptr, b = nullptr;
+    Timed(rtr_ctx *c_, int k_) : c(c_), k(k_) {
+        if (!c->timing) return;
+        if (c->pool.empty()) {
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        } else {
+            a = c->pool.back().first; b = c->pool.back().second; c->pool.pop_back();
+        }
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~Timed() {
+        if (!a) return;
+        (void)hipEventRecord(b, c->stream);
+        c->pending.push_back({a, b, k});
+    }
+};
+
+int collect_timing(rtr_ctx *c) {
+    if (c->pending.empty()) return RTR_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto &s : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            c->total_ms[s.k] += ms;
+            c->launches[s.k] += 1;
+        }
+        c->pool.emplace_back(s.a, s.b);
+    }
+    c->pending.clear();
+    return RTR_OK;
+}
+
+int check_frame(rtr_ctx *c) {
+    NEED(c, c->W > 0 && c->H > 0, "rtr_set_resolution has not been called");
+    return RTR_OK;
+}
+
+int launch_check(rtr_ctx *c, const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, RTR_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
+    return RTR_OK;
+}
+
+int ensure_pyramid(rtr_ctx *c) {
+    const int L = c->prm.levels;
+    if (L < 1 || L > 8) return fail(c, RTR_ERR_UNSUPPORTED, "levels must be in 1..8");
+    if ((c->W % (1 << L)) != 0 || (c->H >> L) < 1)
+        return fail(c, RTR_ERR_UNSUPPORTED,
+                    "prefilter needs W %% 2^levels == 0 and H >= 2^levels (got %dx%d, levels %d): the reference's "
+                    "pyramid strides are only defined then (project_cloud.cu:39,336-362)", c->W, c->H, L);
+    if (c->lv_levels == L) return RTR_OK;
+    for (int i = 1; i <= 8; ++i) dfree(c->lv.lv[i]);
+    c->lv.levels = L;
+    c->lv.lv[0] = reinterpret_cast<float *>(c->depth);
+    c->lv.w[0] = c->W; c->lv.h[0] = c->H;
+    for (int i = 1; i <= L; ++i) {
+        c->lv.w[i] = c->lv.w[i - 1] / 2;
+        c->lv.h[i] = c->lv.h[i - 1] / 2;
+        HIP_TRY(c, hipMalloc((void **)&c->lv.lv[i], sizeof(float) * (size_t)c->lv.w[i] * c->lv.h[i]));
+    }
+    c->lv_levels = L;
+    return RTR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtr_abi_version(void) { return RTR_ABI_VERSION; }
+
+void rtr_default_params(rtr_params *p) {
+    if (!p) return;
+    p->depth_window = 0.02f;        // render.cu:106
+    p->filter_strength = 1.025f;    // project_cloud.cu:24
+    p->gradient_threshold = 0.03f;  // project_cloud.cu:25
+    p->levels = 4;                  // project_cloud.cu:23
+}
+
+int rtr_create(rtr_ctx **out, int device) {
+    if (!out) return fail(nullptr, RTR_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, RTR_ERR_HIP, "no HIP device available (%s): this library has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= ndev) return fail(nullptr, RTR_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    rtr_ctx *c = new rtr_ctx();
+    c->device = device;
+    rtr_default_params(&c->prm);
+    DevGuard g(device);
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, RTR_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        delete c;
+        return rc;
+    }
+    c->stream = c->own_stream;
+    e = hipMalloc((void **)&c->minmax, 2 * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, RTR_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+        (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return RTR_OK;
+}
+
+int rtr_destroy(rtr_ctx *c) {
+    if (!c) return RTR_OK;
+    DevGuard g(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)collect_timing(c);
+    for (auto &p : c->pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    free_frame(c);
+    free_cloud(c);
+    dfree(c->minmax);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return RTR_OK;
+}
+
+const char *rtr_last_error(const rtr_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int rtr_set_params(rtr_ctx *c, const rtr_params *p) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, p != nullptr, "params is NULL");
+    NEED(c, p->levels >= 1 && p->levels <= 8, "levels must be in 1..8");
+    c->prm = *p;
+    return RTR_OK;
+}
+
+int rtr_get_params(const rtr_ctx *c, rtr_params *p) {
+    if (!c || !p) return RTR_ERR_INVALID;
+    *p = c->prm;
+    return RTR_OK;
+}
+
+int rtr_set_stream(rtr_ctx *c, void *s) {
+    if (!c) return RTR_ERR_INVALID;
+    DevGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)collect_timing(c);
+    c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+    return RTR_OK;
+}
+
+int rtr_synchronize(rtr_ctx *c) {
+    if (!c) return RTR_ERR_INVALID;
+    DevGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTR_OK;
+}
+
+// ---- cloud -------------------------------------------------------------------------
+
+int rtr_upload_points(rtr_ctx *c, const float *xyz, size_t xs, const uint8_t *rgb, size_t rs, size_t n) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, n == 0 || (xyz && rgb), "xyz / rgb is NULL");
+    NEED(c, xs >= 12 && xs % 4 == 0, "xyz_stride_bytes must be >= 12 and a multiple of 4");
+    NEED(c, rs >= 3, "rgb_stride_bytes must be >= 3");
+    NEED(c, n < (1ull << 31) * 4ull, "too many points");
+    DevGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = alloc_cloud(c, n);
+    if (rc) return rc;
+    // stage through device chunks; AoS -> SoA on the GPU
+    const uint64_t chunk = 1ull << 24;
+    uint8_t *sx = nullptr, *sc = nullptr;
+    uint64_t m = n < chunk ? n : chunk;
+    if (m) {
+        HIP_TRY(c, hipMalloc((void **)&sx, m * xs));
+        HIP_TRY(c, hipMalloc((void **)&sc, m * rs));
+    }
+    for (uint64_t off = 0; off < n; off += chunk) {
+        uint64_t cnt = (n - off) < chunk ? (n - off) : chunk;
+        HIP_TRY(c, hipMemcpyAsync(sx, (const uint8_t *)xyz + off * xs, cnt * xs, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(sc, rgb + off * rs, cnt * rs, hipMemcpyHostToDevice, c->stream));
+        rtr::launch_aos_to_soa(c->stream, sx, xs, sc, rs, cnt, c->x + off, c->y + off, c->z + off, c->rgba + off);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    rtr::launch_pad_nan(c->stream, c->x, c->y, c->z, c->rgba, n, (n + 3) & ~3ull);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    dfree(sx); dfree(sc);
+    return launch_check(c, "aos_to_soa");
+}
+
+int rtr_generate_synthetic(rtr_ctx *c, int scene, uint64_t seed, uint64_t first, uint64_t count, uint64_t total) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, scene == RTR_SCENE_UNIFORM_BOX || scene == RTR_SCENE_ROOM_SHELL, "unknown scene");
+    NEED(c, first + count <= total, "first + count exceeds total");
+    NEED(c, total < (1ull << 33), "total too large");
+    DevGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = alloc_cloud(c, count);
+    if (rc) return rc;
+    rtr::launch_generate(c->stream, scene, seed, first, count, total, c->x, c->y, c->z, c->rgba);
+    rtr::launch_pad_nan(c->stream, c->x, c->y, c->z, c->rgba, count, (count + 3) & ~3ull);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return launch_check(c, "generate");
+}
+
+int rtr_num_points(const rtr_ctx *c, uint64_t *n) {
+    if (!c || !n) return RTR_ERR_INVALID;
+    *n = c->n;
+    return RTR_OK;
+}
+
+int rtr_download_points(rtr_ctx *c, float *xyzw, uint8_t *rgba, uint64_t first, uint64_t count) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, xyzw && rgba, "output is NULL");
+    NEED(c, first + count <= c->n, "range exceeds the resident cloud");
+    if (count == 0) return RTR_OK;
+    DevGuard g(c->device);
+    const uint64_t chunk = 1ull << 24;
+    uint64_t m = count < chunk ? count : chunk;
+    float *dx = nullptr; uint8_t *dc = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&dx, m * 16));
+    HIP_TRY(c, hipMalloc((void **)&dc, m * 4));
+    for (uint64_t off = 0; off < count; off += chunk) {
+        uint64_t cnt = (count - off) < chunk ? (count - off) : chunk;
+        uint64_t s0 = first + off;
+        rtr::launch_soa_to_aos(c->stream, c->x + s0, c->y + s0, c->z + s0, c->rgba + s0, cnt, dx, dc);
+        HIP_TRY(c, hipMemcpyAsync(xyzw + off * 4, dx, cnt * 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(rgba + off * 4, dc, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    dfree(dx); dfree(dc);
+    return launch_check(c, "soa_to_aos");
+}
+
+// ---- camera ------------------------------------------------------------------------
+
+// project_cloud.cu:318 with project_cloud.h:50-59 and CameraCalibration.cpp:17-27:
+// both glm transposes cancel, leaving P = K4 * E evaluated in fp32 (each entry the
+// left-to-right sum of four separately rounded products), stored row-major.
+int rtr_compose_projection(const double K[9], const double E[16], float P[16]) {
+    if (!K || !E || !P) return RTR_ERR_INVALID;
+    float K4[16] = {0}, Ef[16];
+    for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 3; ++q) K4[4 * r + q] = static_cast<float>(K[3 * r + q]);
+    K4[15] = 1.0f;
+    for (int i = 0; i < 16; ++i) Ef[i] = static_cast<float>(E[i]);
+    for (int r = 0; r < 4; ++r)
+        for (int q = 0; q < 4; ++q) {
+            volatile float s = K4[4 * r + 0] * Ef[q];  // volatile: one rounding per op, no contraction
+            volatile float t = K4[4 * r + 1] * Ef[4 + q];
+            s = s + t;
+            t = K4[4 * r + 2] * Ef[8 + q];
+            s = s + t;
+            t = K4[4 * r + 3] * Ef[12 + q];
+            s = s + t;
+            P[4 * r + q] = s;
+        }
+    return RTR_OK;
+}
+
+int rtr_set_resolution(rtr_ctx *c, int W, int H) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, W > 0 && H > 0 && (int64_t)W * H < (1ll << 31), "bad resolution");
+    if (W == c->W && H == c->H) return RTR_OK;
+    DevGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_frame(c);
+    size_t npix = (size_t)W * H;
+    HIP_TRY(c, hipMalloc((void **)&c->depth, npix * 4));
+    HIP_TRY(c, hipMalloc((void **)&c->acc, npix * 16));
+    HIP_TRY(c, hipMalloc((void **)&c->img, (npix * 3 + 15) & ~(size_t)15));
+    HIP_TRY(c, hipMalloc((void **)&c->mask, npix));
+    HIP_TRY(c, hipMalloc((void **)&c->grad, npix));
+    HIP_TRY(c, hipMalloc((void **)&c->tensor, npix * 5 * sizeof(uint16_t)));
+    c->W = W; c->H = H;
+    return RTR_OK;
+}
+
+// ---- phases ------------------------------------------------------------------------
+
+int rtr_clear(rtr_ctx *c) {
+    if (!c) return RTR_ERR_INVALID;
+    if (int rc = check_frame(c)) return rc;
+    DevGuard g(c->device);
+    { Timed t(c, RTR_K_CLEAR); rtr::launch_clear(c->stream, c->depth, c->acc, (size_t)c->W * c->H); }
+    return launch_check(c, "clear");
+}
+
+int rtr_min_depth_pass(rtr_ctx *c, const float P[16]) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, P != nullptr, "P is NULL");
+    if (int rc = check_frame(c)) return rc;
+    DevGuard g(c->device);
+    { Timed t(c, RTR_K_MIN_DEPTH); rtr::launch_min_depth(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->depth); }
+    return launch_check(c, "min_depth_pass");
+}
+
+int rtr_accumulate_pass(rtr_ctx *c, const float P[16]) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, P != nullptr, "P is NULL");
+    if (int rc = check_frame(c)) return rc;
+    DevGuard g(c->device);
+    {
+        Timed t(c, RTR_K_ACCUMULATE);
+        rtr::launch_accumulate(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->depth, c->acc, c->prm.depth_window);
+    }
+    return launch_check(c, "accumulate_pass");
+}
+
+int rtr_resolve(rtr_ctx *c) {
+    if (!c) return RTR_ERR_INVALID;
+    if (int rc = check_frame(c)) return rc;
+    DevGuard g(c->device);
+    { Timed t(c, RTR_K_RESOLVE); rtr::launch_resolve(c->stream, c->acc, c->img, (size_t)c->W * c->H); }
+    return launch_check(c, "resolve");
+}
+
+int rtr_filter(rtr_ctx *c) {
+    if (!c) return RTR_ERR_INVALID;
+    if (int rc = check_frame(c)) return rc;
+    DevGuard g(c->device);
+    if (int rc = ensure_pyramid(c)) return rc;
+    {
+        Timed t(c, RTR_K_FILTER);
+        rtr::launch_filter(c->stream, c->lv, c->depth, c->img, c->mask, c->grad, c->tensor, c->minmax, c->W, c->H,
+                           c->prm.filter_strength, c->prm.gradient_threshold);
+    }
+    return launch_check(c, "filter");
+}
+
+// ---- whole frames ------------------------------------------------------------------
+
+int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, P != nullptr, "P is NULL");
+    if (int rc = check_frame(c)) return rc;
+    if (with_filter) {  // fail before touching the frame buffers
+        DevGuard g(c->device);
+        if (int rc = ensure_pyramid(c)) return rc;
+    }
+    int rc;
+    if ((rc = rtr_clear(c))) return rc;
+    if ((rc = rtr_min_depth_pass(c, P))) return rc;
+    if ((rc = rtr_accumulate_pass(c, P))) return rc;
+    if ((rc = rtr_resolve(c))) return rc;
+    if (with_filter && (rc = rtr_filter(c))) return rc;
+    return RTR_OK;
+}
+
+static int frame_to_host(rtr_ctx *c, const float P[16], uint8_t *host_img, float *host_depth, int with_filter) {
+    if (!c) return RTR_ERR_INVALID;
+    if (!host_img && !host_depth) return fail(c, RTR_ERR_NO_OUTPUT, "both outputs are NULL (project_cloud.cu:270-273)");
+    int rc = rtr_render(c, P, with_filter);
+    if (rc) return rc;
+    DevGuard g(c->device);
+    size_t npix = (size_t)c->W * c->H;
+    if (host_depth) HIP_TRY(c, hipMemcpyAsync(host_depth, c->depth, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    if (host_img) HIP_TRY(c, hipMemcpyAsync(host_img, c->img, npix * 3, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTR_OK;
+}
+
+int rtr_project(rtr_ctx *c, const float P[16], uint8_t *host_img, float *host_depth) {
+    return frame_to_host(c, P, host_img, host_depth, 0);
+}
+
+int rtr_project_filtered(rtr_ctx *c, const float P[16], uint8_t *host_img, float *host_depth) {
+    return frame_to_host(c, P, host_img, host_depth, 1);
+}
+
+// ---- buffers -----------------------------------------------------------------------
+
+int rtr_device_buffer(rtr_ctx *c, int which, void **ptr, size_t *bytes) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, ptr != nullptr, "dev_ptr is NULL");
+    if (which != RTR_BUF_MINMAX)
+        if (int rc = check_frame(c)) return rc;
+    size_t npix = (size_t)c->W * c->H, b = 0;
+    void *p = nullptr;
+    switch (which) {
+        case RTR_BUF_DEPTH: p = c->depth; b = npix * 4; break;
+        case RTR_BUF_ACCUM: p = c->acc; b = npix * 16; break;
+        case RTR_BUF_IMAGE: p = c->img; b = npix * 3; break;
+        case RTR_BUF_TENSOR: p = c->tensor; b = npix * 10; break;
+        case RTR_BUF_MASK: p = c->mask; b = npix; break;
+        case RTR_BUF_MINMAX: p = c->minmax; b = 8; break;
+        default: return fail(c, RTR_ERR_INVALID, "unknown buffer id %d", which);
+    }
+    *ptr = p;
+    if (bytes) *bytes = b;
+    return RTR_OK;
+}
+
+int rtr_download_buffer(rtr_ctx *c, int which, void *host, size_t bytes) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, host != nullptr, "host is NULL");
+    void *p = nullptr; size_t b = 0;
+    int rc = rtr_device_buffer(c, which, &p, &b);
+    if (rc) return rc;
+    NEED(c, bytes == b, "size mismatch");
+    DevGuard g(c->device);
+    HIP_TRY(c, hipMemcpyAsync(host, p, b, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTR_OK;
+}
+
+// ---- measurement -------------------------------------------------------------------
+
+int rtr_timing_enable(rtr_ctx *c, int on) {
+    if (!c) return RTR_ERR_INVALID;
+    DevGuard g(c->device);
+    (void)collect_timing(c);
+    c->timing = on != 0;
+    return RTR_OK;
+}
+
+int rtr_timing_reset(rtr_ctx *c) {
+    if (!c) return RTR_ERR_INVALID;
+    DevGuard g(c->device);
+    (void)collect_timing(c);
+    for (int k = 0; k < RTR_K_COUNT; ++k) { c->total_ms[k] = 0; c->launches[k] = 0; }
+    return RTR_OK;
+}
+
+int rtr_timing_get(rtr_ctx *c, int k, double *total_ms, uint64_t *launches) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, k >= 0 && k < RTR_K_COUNT, "bad kernel id");
+    DevGuard g(c->device);
+    if (int rc = collect_timing(c)) return rc;
+    if (total_ms) *total_ms = c->total_ms[k];
+    if (launches) *launches = c->launches[k];
+    return RTR_OK;
+}
+
+}  // extern "C"

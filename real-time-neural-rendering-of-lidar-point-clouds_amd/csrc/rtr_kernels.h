@@ -1,0 +1,43 @@
+// rtr_kernels.h -- launch wrappers of the gfx950 kernels (internal to librtr_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtr {
+
+// Rows 0..2 of the row-major camera matrix (row 3 is never used: render.cu:33-40
+// computes result.w but nothing reads it).  Passed BY VALUE so the twelve floats
+// live in SGPRs -- the reference pays a synchronous 64-byte H2D copy per frame
+// (project_cloud.cu:320).
+struct Proj {
+    float m[12];
+};
+
+struct Cloud {
+    const float *x, *y, *z;  // SoA, padded to a multiple of 4 points with NaN
+    const uint32_t *rgba;    // packed c0 | c1<<8 | c2<<16 | 255<<24
+    uint64_t n;              // real point count
+};
+
+struct FilterLevels {
+    float *lv[9];  // lv[0] = depth buffer (as float), lv[i] = level i
+    int w[9], h[9];
+    int levels;
+};
+
+void launch_clear(hipStream_t s, uint32_t *depth, uint32_t *acc, size_t npix);
+void launch_min_depth(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *depth);
+void launch_accumulate(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const uint32_t *depth,
+                       uint32_t *acc, float window);
+void launch_resolve(hipStream_t s, const uint32_t *acc, uint8_t *img, size_t npix);
+void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, uint8_t *img, uint8_t *mask,
+                   uint8_t *grad, uint16_t *tensor, uint32_t *minmax, int W, int H, float strength, float thr);
+void launch_generate(hipStream_t s, int scene, uint64_t seed, uint64_t first, uint64_t count, uint64_t total,
+                     float *x, float *y, float *z, uint32_t *rgba);
+void launch_aos_to_soa(hipStream_t s, const uint8_t *xyz, size_t xyz_stride, const uint8_t *rgb, size_t rgb_stride,
+                       uint64_t count, float *x, float *y, float *z, uint32_t *rgba);
+void launch_soa_to_aos(hipStream_t s, const float *x, const float *y, const float *z, const uint32_t *rgba,
+                       uint64_t count, float *xyzw, uint8_t *rgba_out);
+void launch_pad_nan(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, uint64_t n, uint64_t n_pad);
+
+}  // namespace rtr

@@ -1,0 +1,226 @@
+"""Host-side mirror of the reference's ProjectCloud on top of the C ABI.
+
+`Projector` is a 1:1 wrapper of include/rtr.h.  `ProjectCloud` keeps the reference's
+public interface (reference: src/RTRenderer/include/project_cloud.h:11-19 and
+src/project_cloud.cu:268-434): same method names, argument meaning (calibration,
+world->camera extrinsics, optional caller-allocated colour / depth outputs) and return
+codes (1 ok, -1 when both outputs are None).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .camera import compose_projection
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceBuffer:
+    """A context-owned device buffer exposed through __cuda_array_interface__ so that
+    torch.as_tensor(buf, device='cuda') aliases it (zero copy) for RCCL collectives."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.ptr, self.shape, self.typestr = ptr, tuple(shape), typestr
+        self.__cuda_array_interface__ = {"shape": self.shape, "typestr": typestr, "data": (ptr, False),
+                                         "version": 2, "strides": None}
+
+
+class Projector:
+    """Thin object wrapper over the rtr_* C ABI (one context = one GPU)."""
+
+    def __init__(self, device=0):
+        self._lib = L.lib()
+        self._ctx = C.c_void_p()
+        rc = self._lib.rtr_create(C.byref(self._ctx), int(device))
+        if rc != 0:
+            raise L.RtrError(rc, (self._lib.rtr_last_error(None) or b"").decode())
+        self.device = int(device)
+        self.W = self.H = 0
+
+    # -- plumbing
+    def _chk(self, rc):
+        if rc != 0:
+            raise L.RtrError(rc, (self._lib.rtr_last_error(self._ctx) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.rtr_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._chk(self._lib.rtr_synchronize(self._ctx))
+
+    def set_stream(self, hip_stream_ptr):
+        self._chk(self._lib.rtr_set_stream(self._ctx, C.c_void_p(hip_stream_ptr or 0)))
+
+    @property
+    def params(self):
+        p = L.RtrParams()
+        self._chk(self._lib.rtr_get_params(self._ctx, C.byref(p)))
+        return p
+
+    def set_params(self, **kw):
+        p = self.params
+        for k, v in kw.items():
+            setattr(p, k, v)
+        self._chk(self._lib.rtr_set_params(self._ctx, C.byref(p)))
+
+    # -- cloud
+    def upload_points(self, xyz, rgb):
+        """xyz: float32 [n,3|4] (the reference's float4 (x,y,z,1) or tight xyz);
+        rgb: uint8 [n,3|4] (uchar4 (c0,c1,c2,255) or tight triples)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        if xyz.ndim != 2 or xyz.shape[1] not in (3, 4) or rgb.ndim != 2 or rgb.shape[1] not in (3, 4) \
+                or rgb.shape[0] != xyz.shape[0]:
+            raise ValueError("xyz must be [n,3|4] float32 and rgb [n,3|4] uint8 with equal n")
+        self._chk(self._lib.rtr_upload_points(self._ctx, _vp(xyz), xyz.shape[1] * 4, _vp(rgb), rgb.shape[1],
+                                              xyz.shape[0]))
+
+    def generate_synthetic(self, scene, seed, first, count, total):
+        sc = L.SCENES[scene] if isinstance(scene, str) else int(scene)
+        self._chk(self._lib.rtr_generate_synthetic(self._ctx, sc, seed, first, count, total))
+
+    @property
+    def num_points(self):
+        n = C.c_uint64()
+        self._chk(self._lib.rtr_num_points(self._ctx, C.byref(n)))
+        return n.value
+
+    def download_points(self, first=0, count=None):
+        count = self.num_points - first if count is None else count
+        xyzw = np.empty((count, 4), np.float32)
+        rgba = np.empty((count, 4), np.uint8)
+        self._chk(self._lib.rtr_download_points(self._ctx, _vp(xyzw), _vp(rgba), first, count))
+        return xyzw, rgba
+
+    # -- frames
+    def set_resolution(self, W, H):
+        self._chk(self._lib.rtr_set_resolution(self._ctx, int(W), int(H)))
+        self.W, self.H = int(W), int(H)
+
+    @staticmethod
+    def _P(P):
+        P = np.ascontiguousarray(P, dtype=np.float32).reshape(16)
+        return P
+
+    def project(self, P, want_img=True, want_depth=True, filtered=False):
+        """-> (img uint8 [H,W,3] | None, depth float32 [H,W] | None)"""
+        P = self._P(P)
+        img = np.empty((self.H, self.W, 3), np.uint8) if want_img else None
+        depth = np.empty((self.H, self.W), np.float32) if want_depth else None
+        fn = self._lib.rtr_project_filtered if filtered else self._lib.rtr_project
+        self._chk(fn(self._ctx, _vp(P), _vp(img), _vp(depth)))
+        return img, depth
+
+    def render(self, P, with_filter=False):
+        P = self._P(P)
+        self._chk(self._lib.rtr_render(self._ctx, _vp(P), 1 if with_filter else 0))
+
+    # -- phases (multi-GPU: reduce the device buffers between them)
+    def clear(self):
+        self._chk(self._lib.rtr_clear(self._ctx))
+
+    def min_depth_pass(self, P):
+        P = self._P(P)
+        self._chk(self._lib.rtr_min_depth_pass(self._ctx, _vp(P)))
+
+    def accumulate_pass(self, P):
+        P = self._P(P)
+        self._chk(self._lib.rtr_accumulate_pass(self._ctx, _vp(P)))
+
+    def resolve(self):
+        self._chk(self._lib.rtr_resolve(self._ctx))
+
+    def filter(self):
+        self._chk(self._lib.rtr_filter(self._ctx))
+
+    # -- buffers
+    _BUF = {L.BUF_DEPTH: (np.uint32, "<u4", lambda w, h: (h, w)),
+            L.BUF_ACCUM: (np.uint32, "<u4", lambda w, h: (h, w, 4)),
+            L.BUF_IMAGE: (np.uint8, "|u1", lambda w, h: (h, w, 3)),
+            L.BUF_TENSOR: (np.uint16, "<f2", lambda w, h: (1, 5, h, w)),
+            L.BUF_MASK: (np.uint8, "|u1", lambda w, h: (h, w)),
+            L.BUF_MINMAX: (np.uint32, "<u4", lambda w, h: (2,))}
+
+    def device_buffer(self, which, typestr=None):
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        self._chk(self._lib.rtr_device_buffer(self._ctx, which, C.byref(ptr), C.byref(nbytes)))
+        _, ts, shp = self._BUF[which]
+        return DeviceBuffer(ptr.value, shp(self.W, self.H), typestr or ts)
+
+    def download(self, which):
+        dt, _, shp = self._BUF[which]
+        out = np.empty(shp(self.W, self.H), dt)
+        self._chk(self._lib.rtr_download_buffer(self._ctx, which, _vp(out), out.nbytes))
+        return out
+
+    # -- measurement
+    def timing_enable(self, on=True):
+        self._chk(self._lib.rtr_timing_enable(self._ctx, 1 if on else 0))
+
+    def timing_reset(self):
+        self._chk(self._lib.rtr_timing_reset(self._ctx))
+
+    def timing(self):
+        """-> {kernel name: (total_ms, launches)} (synchronises the stream)"""
+        out = {}
+        for k, name in enumerate(L.KERNEL_NAMES):
+            ms, n = C.c_double(), C.c_uint64()
+            self._chk(self._lib.rtr_timing_get(self._ctx, k, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+
+class ProjectCloud:
+    """Drop-in mirror of the reference class (project_cloud.h:11-19).
+
+    ctor: the reference flattens its grid into float4 / uchar4 arrays
+    (project_cloud.cu:191-192, Octreegrid.h:162-180); here the caller passes those
+    flattened arrays (or tight xyz / rgb) directly.  `modelFilename` is accepted for
+    signature compatibility; the libtorch U-Net consumer stays outside this library and
+    reads the device tensor via `tensor_device_buffer()` (project_cloud.cu:471)."""
+
+    def __init__(self, vertices, colors, modelFilename="", device=0):
+        self._p = Projector(device)
+        self._p.upload_points(vertices, colors)
+        self.modelFilename = modelFilename
+
+    @property
+    def projector(self):
+        return self._p
+
+    def _frame(self, calibration, extrinsics, color, depth, filtered):
+        if color is None and depth is None:  # project_cloud.cu:270-273
+            return -1
+        W, H = calibration.getWidth(), calibration.getHeight()
+        for name, arr, shape, dt in (("color", color, (H, W, 3), np.uint8), ("depth", depth, (H, W), np.float32)):
+            if arr is not None and (arr.dtype != dt or arr.shape != shape or not arr.flags.c_contiguous):
+                raise ValueError("%s must be a C-contiguous %s array of shape %s (main.cpp:93-94)" % (name, dt, shape))
+        self._p.set_resolution(W, H)  # project_cloud.cu:275-298
+        P = compose_projection(calibration.getIntrinsicsMatrix(), extrinsics)  # project_cloud.cu:318
+        fn = self._p._lib.rtr_project_filtered if filtered else self._p._lib.rtr_project
+        self._p._chk(fn(self._p._ctx, _vp(P), _vp(color), _vp(depth)))
+        return 1
+
+    def computeRGBD(self, calibration, extrinsics, color, depth):
+        """project_cloud.cu:268-312.  extrinsics = world->camera 4x4 (main.cpp:96)."""
+        return self._frame(calibration, extrinsics, color, depth, False)
+
+    def computeFilteredRGBD(self, calibration, extrinsics, color, depth):
+        """project_cloud.cu:394-434."""
+        return self._frame(calibration, extrinsics, color, depth, True)
+
+    def tensor_device_buffer(self):
+        """The planar fp16 {1,5,H,W} device tensor computeFull feeds to the U-Net
+        (project_cloud.cu:471); valid after computeFilteredRGBD."""
+        return self._p.device_buffer(L.BUF_TENSOR)

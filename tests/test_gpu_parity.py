@@ -1,0 +1,139 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Bars (BASELINE.json north_star): pixel indices / depth bits / colour bytes / mask / fp16
+tensor bits identical (this implies the <= 1e-5 float-depth criterion).
+"""
+import numpy as np
+import pytest
+
+from helpers import cloud, kat_P, random_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_frame(pkg, orc, projector, xyzw, rgba, P, W, H, filtered=True):
+    projector.upload_points(xyzw, rgba)
+    projector.set_resolution(W, H)
+    img, depth = projector.project(P)
+    ref = orc.project(xyzw, rgba, P, W, H)
+    assert np.array_equal(depth.view(np.uint32), ref["depth_bits"])
+    assert np.array_equal(projector.download(pkg._lib.BUF_ACCUM), ref["acc"])
+    assert np.array_equal(img, ref["img"])
+    assert np.max(np.abs(depth[ref["depth_bits"] != orc.EMPTY_DEPTH] -
+                         ref["depth_bits"].view(np.float32)[ref["depth_bits"] != orc.EMPTY_DEPTH]), initial=0) <= 1e-5
+    if filtered:
+        img_f, depth_f = projector.project(P, filtered=True)
+        rf = orc.filter(ref["depth_bits"], ref["img"])
+        assert np.array_equal(projector.download(pkg._lib.BUF_MASK), rf["mask"])
+        assert np.array_equal(depth_f.view(np.uint32), rf["depth"].view(np.uint32))
+        assert np.array_equal(img_f, rf["img"])
+        assert np.array_equal(projector.download(pkg._lib.BUF_MINMAX), rf["minmax"])
+        assert np.array_equal(projector.download(pkg._lib.BUF_TENSOR).reshape(5, H, W), rf["tensor"])
+    return ref
+
+
+@pytest.mark.parametrize("scene", ["uniform_box", "room_shell"])
+@pytest.mark.parametrize("W,H", [(640, 480), (1920, 1080), (64, 48)])
+def test_scene_frame_parity(pkg, orc, projector, scene, W, H):
+    n = 200_000
+    xyzw, rgba = orc.generate(scene, 0xC0FFEE01, 0, n, n)
+    for k in (0, 137, 500):
+        ref = _check_frame(pkg, orc, projector, xyzw, rgba, pkg.orbit_projection(k, W, H), W, H)
+    assert (ref["depth_bits"] != orc.EMPTY_DEPTH).sum() > 0
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 255, 257, 1023, 4099])
+def test_ragged_point_counts(pkg, orc, projector, n):
+    xyzw, rgba = random_cloud(n, seed=n + 1)
+    _check_frame(pkg, orc, projector, xyzw, rgba, pkg.orbit_projection(10, 64, 48), 64, 48)
+
+
+def test_kat_points(pkg, orc, projector):
+    P = kat_P(orc)
+    pts = [(0, 0, 2), (0, 0, 0), (0, 0, -1), (0, 0, 1e-30), (-0.32, 0, 1.0), (-0.325, 0, 1.0), (0.315, 0, 1.0),
+           (0.0, 0.0, 1.0), (0.0, 0.0, 1.01), (0.0, 0.0, 1.03)]
+    cols = [(10 * i, 20, 255 - i) for i in range(len(pts))]
+    xyzw, rgba = cloud(pts, cols)
+    _check_frame(pkg, orc, projector, xyzw, rgba, P, 64, 48)
+
+
+def test_collisions_one_pixel(pkg, orc, projector):
+    """300 identical points in one pixel plus a far crowd behind them (atomic contention)."""
+    P = kat_P(orc)
+    pts = [(0, 0, 2.0)] * 300 + [(0, 0, 2.015)] * 200 + [(0, 0, 2.5)] * 100
+    cols = [(255, 255, 255)] * 300 + [(1, 2, 3)] * 200 + [(9, 9, 9)] * 100
+    xyzw, rgba = cloud(pts, cols)
+    ref = _check_frame(pkg, orc, projector, xyzw, rgba, P, 64, 48)
+    assert ref["acc"][24, 32, 3] == 500
+
+
+def test_shuffle_and_shard_invariance(pkg, orc, projector):
+    n, W, H = 100_000, 640, 480
+    xyzw, rgba = orc.generate("room_shell", 7, 0, n, n)
+    P = pkg.orbit_projection(42, W, H)
+    projector.upload_points(xyzw, rgba)
+    projector.set_resolution(W, H)
+    img0, d0 = projector.project(P)
+    perm = np.random.default_rng(0).permutation(n)
+    projector.upload_points(xyzw[perm], rgba[perm])
+    img1, d1 = projector.project(P)
+    assert np.array_equal(img0, img1) and np.array_equal(d0.view(np.uint32), d1.view(np.uint32))
+
+
+def test_generator_matches_oracle(pkg, orc, projector):
+    for scene in ("uniform_box", "room_shell"):
+        total = 1_000_003
+        for first, count in ((0, 5000), (500_000, 4097), (total - 333, 333)):
+            projector.generate_synthetic(scene, 0xC0FFEE03, first, count, total)
+            xyzw, rgba = projector.download_points()
+            rx, rc = orc.generate(scene, 0xC0FFEE03, first, count, total)
+            assert np.array_equal(xyzw.view(np.uint32), rx.view(np.uint32)), scene
+            assert np.array_equal(rgba, rc), scene
+
+
+def test_phase_calls_equal_whole_frame(pkg, orc, projector):
+    n, W, H = 50_000, 320, 240
+    xyzw, rgba = orc.generate("uniform_box", 11, 0, n, n)
+    P = pkg.orbit_projection(5, W, H)
+    projector.upload_points(xyzw, rgba)
+    projector.set_resolution(W, H)
+    img0, d0 = projector.project(P)
+    projector.clear()
+    projector.min_depth_pass(P)
+    projector.accumulate_pass(P)
+    projector.resolve()
+    projector.synchronize()
+    assert np.array_equal(projector.download(pkg._lib.BUF_IMAGE), img0)
+    assert np.array_equal(projector.download(pkg._lib.BUF_DEPTH), d0.view(np.uint32))
+
+
+def test_project_cloud_mirror(pkg, orc):
+    n, W, H = 20_000, 160, 128
+    xyzw, rgba = orc.generate("room_shell", 3, 0, n, n)
+    pc = pkg.ProjectCloud(xyzw, rgba)
+    cal = pkg.benchmark_calibration(W, H)
+    E = pkg.orbit_pose(77)
+    color = np.empty((H, W, 3), np.uint8)
+    depth = np.empty((H, W), np.float32)
+    assert pc.computeRGBD(cal, E, None, None) == -1
+    assert pc.computeRGBD(cal, E, color, depth) == 1
+    ref = orc.project(xyzw, rgba, orc.compose_projection(cal.getIntrinsicsMatrix(), E), W, H)
+    assert np.array_equal(color, ref["img"]) and np.array_equal(depth.view(np.uint32), ref["depth_bits"])
+    d2 = np.empty((H, W), np.float32)
+    assert pc.computeRGBD(cal, E, None, d2) == 1  # depth-only use (cloudreader.cpp:246)
+    assert np.array_equal(d2, depth)
+    assert pc.computeFilteredRGBD(cal, E, color, depth) == 1
+    rf = orc.filter(ref["depth_bits"], ref["img"])
+    assert np.array_equal(color, rf["img"]) and np.array_equal(depth.view(np.uint32), rf["depth"].view(np.uint32))
+    pc.projector.close()
+
+
+def test_errors(pkg, projector):
+    projector.set_resolution(100, 50)  # W % 16 != 0
+    P = pkg.orbit_projection(0, 100, 50)
+    with pytest.raises(pkg.RtrError) as e:
+        projector.project(P, filtered=True)
+    assert e.value.code == pkg._lib.RTR_ERR_UNSUPPORTED
+    with pytest.raises(pkg.RtrError) as e:
+        projector.project(P, want_img=False, want_depth=False)
+    assert e.value.code == pkg._lib.RTR_ERR_NO_OUTPUT
