@@ -18,13 +18,13 @@ SYMBOLS = [
     "rtr_num_points", "rtr_download_points", "rtr_compose_projection", "rtr_set_resolution", "rtr_project",
     "rtr_project_filtered", "rtr_render", "rtr_clear", "rtr_min_depth_pass", "rtr_accumulate_pass", "rtr_resolve",
     "rtr_filter", "rtr_device_buffer", "rtr_download_buffer", "rtr_timing_enable", "rtr_timing_reset",
-    "rtr_timing_get",
+    "rtr_timing_get", "rtr_set_option", "rtr_stream_probe",
 ]
 
 RTR_OK, RTR_ERR_INVALID, RTR_ERR_HIP, RTR_ERR_NO_OUTPUT, RTR_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 BUF_DEPTH, BUF_ACCUM, BUF_IMAGE, BUF_TENSOR, BUF_MASK, BUF_MINMAX = range(6)
-K_CLEAR, K_MIN_DEPTH, K_ACCUMULATE, K_RESOLVE, K_FILTER = range(5)
-KERNEL_NAMES = ["clear", "min_depth", "accumulate", "resolve", "filter"]
+K_CLEAR, K_MIN_DEPTH, K_ACCUMULATE, K_RESOLVE, K_FILTER, K_PROBE, K_TILE, K_BIN = range(8)
+KERNEL_NAMES = ["clear", "min_depth", "accumulate", "resolve", "filter", "probe", "tile", "bin"]
 SCENES = {"uniform_box": 0, "room_shell": 1}
 EMPTY_DEPTH = 0x7F7FFFFF
 
@@ -88,6 +88,8 @@ def lib():
     L.rtr_download_buffer.argtypes = [vp, i32, vp, sz]
     L.rtr_timing_enable.argtypes = [vp, i32]
     L.rtr_timing_reset.argtypes = [vp]
+    L.rtr_set_option.argtypes = [vp, C.c_char_p, i32]
+    L.rtr_stream_probe.argtypes = [vp, vp]
     L.rtr_timing_get.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64)]
     for name in SYMBOLS:
         fn = getattr(L, name)

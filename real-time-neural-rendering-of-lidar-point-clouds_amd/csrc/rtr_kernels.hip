@@ -15,9 +15,11 @@ namespace rtr {
 constexpr int kBlock = 256;   // 4 waves
 constexpr int kPtGrid = 2048; // 256 CUs x 8 resident blocks, grid-stride the rest
 
-__device__ __forceinline__ float f_mul(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float f_add(float a, float b) { return __fadd_rn(a, b); }
-__device__ __forceinline__ float f_sub(float a, float b) { return __fsub_rn(a, b); }
+// one rounding per operation: plain operators under -ffp-contract=off (hipcc's __fmul_rn &
+// co. are the same plain operators; __fsqrt_rn is NOT correctly rounded, sqrtf is)
+__device__ __forceinline__ float f_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float f_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float f_sub(float a, float b) { return a - b; }
 
 // ---------------------------------------------------------------------------------
 // projection of one point: render.cu:33-40 (matmul rows 0..2), :63 (z cull),
@@ -59,91 +61,482 @@ void launch_clear(hipStream_t s, uint32_t *depth, uint32_t *acc, size_t npix) {
 }
 
 // ---------------------------------------------------------------------------------
-// A4 minDepthPass (render.cu:53-83).  Semantics = "atomicMin of every surviving
-// point"; the reference's __match_any_sync aggregation is only a contention trick.
-// Here: SoA float4 loads (1 KiB per wave-instruction per coordinate), early-z (skip
-// the atomic unless strictly closer than what an L1-bypassing load sees).  A stale
-// early-z value can only cause a redundant atomic, never a wrong result.
-__device__ __forceinline__ void zmin(uint32_t *depth, int pix, float d) {
-    if (pix < 0) return;
-    uint32_t b = __float_as_uint(d);
-    uint32_t cur = __hip_atomic_load(&depth[pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (b < cur) atomicMin(&depth[pix], b);
+// Point passes.  Both stream the SoA cloud with 16-byte non-temporal loads (1 KiB per
+// wave-instruction per coordinate; `nt` keeps the 1.2 GB stream from evicting the
+// frame buffers out of L2 / Infinity Cache) and project four points per lane.
+struct Quad {
+    int pix[4];
+    float d[4];
+};
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream(const float4 *p) {
+    v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint4 ld_stream(const uint4 *p) {
+    v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+__device__ __forceinline__ Quad project_quad(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
+                                             const float4 *__restrict__ z4, uint64_t i, const Proj &P, int W, int H,
+                                             float fW, float fH) {
+    float4 X = ld_stream(x4 + i), Y = ld_stream(y4 + i), Z = ld_stream(z4 + i);
+    Quad q;
+    q.pix[0] = project_point(P, X.x, Y.x, Z.x, W, H, fW, fH, q.d[0]);
+    q.pix[1] = project_point(P, X.y, Y.y, Z.y, W, H, fW, fH, q.d[1]);
+    q.pix[2] = project_point(P, X.z, Y.z, Z.z, W, H, fW, fH, q.d[2]);
+    q.pix[3] = project_point(P, X.w, Y.w, Z.w, W, H, fW, fH, q.d[3]);
+    return q;
+}
+
+__device__ __forceinline__ uint32_t ld_fresh(const uint32_t *p) {  // sc1: bypass the CU's L1
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// A4 minDepthPass (render.cu:53-83).  Semantics = "atomicMin of every surviving point";
+// the reference's __match_any_sync aggregation is only a contention trick.  Here:
+//  * early-z: the atomic is skipped unless the point is strictly closer than what an
+//    L1-bypassing load sees.  A stale value is >= the true minimum, so staleness can only
+//    cause a redundant atomic, never a wrong result.  The four loads of a lane are issued
+//    together (culled points read a dummy pixel) so their latencies overlap.
+//  * COMPACT: every in-frustum point that can still pass the accumulate pass's window
+//    test (render.cu:106) is appended as (pixel, depth bits, point index) to a list
+//    private to the wave, so the accumulate pass never re-reads the cloud.  Dropping
+//    d > cur + window is safe: cur >= final minimum and fp32 add is monotone, hence
+//    d > final + window as well.  Wave-private regions need no atomics and no LDS: the
+//    write position is a wave-uniform counter advanced by ballot popcounts.
+template <bool COMPACT>
 __global__ __launch_bounds__(kBlock) void k_min_depth(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
                                                       const float4 *__restrict__ z4, uint64_t n4, Proj P, int W, int H,
-                                                      uint32_t *__restrict__ depth) {
+                                                      uint32_t *__restrict__ depth, float window,
+                                                      uint4 *__restrict__ list, uint32_t *__restrict__ counts,
+                                                      uint64_t region_cap) {
     const float fW = (float)W, fH = (float)H;
-    uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
-        float4 X = x4[i], Y = y4[i], Z = z4[i];
-        float d0, d1, d2, d3;
-        int p0 = project_point(P, X.x, Y.x, Z.x, W, H, fW, fH, d0);
-        int p1 = project_point(P, X.y, Y.y, Z.y, W, H, fW, fH, d1);
-        int p2 = project_point(P, X.z, Y.z, Z.z, W, H, fW, fH, d2);
-        int p3 = project_point(P, X.w, Y.w, Z.w, W, H, fW, fH, d3);
-        zmin(depth, p0, d0);
-        zmin(depth, p1, d1);
-        zmin(depth, p2, d2);
-        zmin(depth, p3, d3);
+    const uint64_t gtid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const int lane = threadIdx.x & 63;
+    uint4 *my = COMPACT ? list + (gtid >> 6) * region_cap : nullptr;
+    uint32_t fill = 0;
+    for (uint64_t i = gtid; i < n4; i += stride) {
+        Quad q = project_quad(x4, y4, z4, i, P, W, H, fW, fH);
+        bool any = (q.pix[0] & q.pix[1] & q.pix[2] & q.pix[3]) >= 0;  // some sign bit clear
+        if (__ballot(any) == 0ull) continue;                          // wave-uniform skip
+        uint32_t cur[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cur[k] = ld_fresh(depth + (q.pix[k] >= 0 ? q.pix[k] : lane));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t b = __float_as_uint(q.d[k]);
+            bool in = q.pix[k] >= 0;
+            if (in && b < cur[k]) atomicMin(&depth[q.pix[k]], b);
+            if (COMPACT) {
+                bool keep = in && !(q.d[k] > f_add(__uint_as_float(cur[k]), window));
+                unsigned long long m = __ballot(keep);
+                if (keep) {
+                    uint32_t pos = fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    my[pos] = make_uint4((uint32_t)q.pix[k], b, (uint32_t)(4 * i + k), 0u);
+                }
+                fill += (uint32_t)__popcll(m);
+            }
+        }
     }
+    if (COMPACT && lane == 0) counts[gtid >> 6] = fill;
 }
 
-void launch_min_depth(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *depth) {
+static int point_grid(uint64_t n4) {
+    uint64_t blocks = (n4 + kBlock - 1) / kBlock;
+    return (int)(blocks < (uint64_t)kPtGrid ? blocks : (uint64_t)kPtGrid);
+}
+
+uint64_t list_region_cap(uint64_t n) {  // entries one wave can produce: its iterations x 64 lanes x 4 points
+    uint64_t n4 = (n + 3) / 4;
+    if (n4 == 0) return 0;
+    uint64_t threads = (uint64_t)point_grid(n4) * kBlock;
+    return ((n4 + threads - 1) / threads) * 256;
+}
+
+uint64_t list_num_waves(uint64_t n) {
+    uint64_t n4 = (n + 3) / 4;
+    return n4 ? (uint64_t)point_grid(n4) * (kBlock / 64) : 0;
+}
+
+void launch_min_depth(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *depth, float window,
+                      uint4 *list, uint32_t *counts) {
     uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) return;
-    uint64_t blocks = (n4 + kBlock - 1) / kBlock;
-    int grid = (int)(blocks < (uint64_t)kPtGrid ? blocks : (uint64_t)kPtGrid);
-    hipLaunchKernelGGL(k_min_depth, dim3(grid), dim3(kBlock), 0, s, (const float4 *)c.x, (const float4 *)c.y,
-                       (const float4 *)c.z, n4, P, W, H, depth);
+    int grid = point_grid(n4);
+    if (list)
+        hipLaunchKernelGGL(k_min_depth<true>, dim3(grid), dim3(kBlock), 0, s, (const float4 *)c.x, (const float4 *)c.y,
+                           (const float4 *)c.z, n4, P, W, H, depth, window, list, counts, list_region_cap(c.n));
+    else
+        hipLaunchKernelGGL(k_min_depth<false>, dim3(grid), dim3(kBlock), 0, s, (const float4 *)c.x,
+                           (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, depth, window, nullptr, nullptr, 0);
 }
 
 // ---------------------------------------------------------------------------------
-// A5 accumulatePass (render.cu:85-130): re-project, depth-window test against the
-// (global) minimum, integer colour sums.
-__device__ __forceinline__ void zacc(const uint32_t *__restrict__ depth, uint32_t *__restrict__ acc,
-                                     const uint32_t *__restrict__ rgba, uint64_t idx, int pix, float d, float window) {
-    if (pix < 0) return;
-    float m = __uint_as_float(depth[pix]);
-    if (d > f_add(m, window)) return;  // render.cu:106
-    uint32_t c = rgba[idx];
-    uint32_t *a = acc + 4 * (size_t)pix;
-    atomicAdd(a + 0, c & 0xFFu);
-    atomicAdd(a + 1, (c >> 8) & 0xFFu);
-    atomicAdd(a + 2, (c >> 16) & 0xFFu);
-    atomicAdd(a + 3, 1u);
+// A5 accumulatePass (render.cu:85-130): depth-window test against the (global) minimum,
+// integer colour sums.  The four u32 accumulators of a pixel (sum c0, sum c1, sum c2,
+// count; project_cloud.h:33) are updated with TWO 64-bit atomic adds on the same memory
+// layout: (c0 | c1 << 32) and (c2 | count << 32).  Identical to four u32 adds unless a
+// single channel sum passes 2^32, where the reference itself wraps (> 16.8 M points in
+// one pixel's window).
+__device__ __forceinline__ void acc_add(uint32_t *__restrict__ acc, int pix, uint32_t c) {
+    unsigned long long *a = reinterpret_cast<unsigned long long *>(acc) + 2 * (size_t)pix;
+    atomicAdd(a + 0, (unsigned long long)(c & 0xFFu) | ((unsigned long long)((c >> 8) & 0xFFu) << 32));
+    atomicAdd(a + 1, (unsigned long long)((c >> 16) & 0xFFu) | (1ull << 32));
 }
 
+// two-pass form: re-project the whole cloud (what the reference does)
 __global__ __launch_bounds__(kBlock) void k_accumulate(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
                                                        const float4 *__restrict__ z4,
                                                        const uint32_t *__restrict__ rgba, uint64_t n4, Proj P, int W,
                                                        int H, const uint32_t *__restrict__ depth,
                                                        uint32_t *__restrict__ acc, float window) {
     const float fW = (float)W, fH = (float)H;
+    const int lane = threadIdx.x & 63;
     uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
-        float4 X = x4[i], Y = y4[i], Z = z4[i];
-        float d0, d1, d2, d3;
-        int p0 = project_point(P, X.x, Y.x, Z.x, W, H, fW, fH, d0);
-        int p1 = project_point(P, X.y, Y.y, Z.y, W, H, fW, fH, d1);
-        int p2 = project_point(P, X.z, Y.z, Z.z, W, H, fW, fH, d2);
-        int p3 = project_point(P, X.w, Y.w, Z.w, W, H, fW, fH, d3);
-        zacc(depth, acc, rgba, 4 * i + 0, p0, d0, window);
-        zacc(depth, acc, rgba, 4 * i + 1, p1, d1, window);
-        zacc(depth, acc, rgba, 4 * i + 2, p2, d2, window);
-        zacc(depth, acc, rgba, 4 * i + 3, p3, d3, window);
+        Quad q = project_quad(x4, y4, z4, i, P, W, H, fW, fH);
+        bool any = (q.pix[0] & q.pix[1] & q.pix[2] & q.pix[3]) >= 0;
+        if (__ballot(any) == 0ull) continue;
+        uint32_t m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = depth[q.pix[k] >= 0 ? q.pix[k] : lane];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (q.pix[k] >= 0 && !(q.d[k] > f_add(__uint_as_float(m[k]), window)))  // render.cu:106
+                acc_add(acc, q.pix[k], rgba[4 * i + k]);
+        }
+    }
+}
+
+// compact form: consume the per-wave survivor lists written by k_min_depth<true>
+__global__ __launch_bounds__(kBlock) void k_accumulate_list(const uint4 *__restrict__ list,
+                                                            const uint32_t *__restrict__ counts, uint64_t region_cap,
+                                                            const uint32_t *__restrict__ rgba,
+                                                            const uint32_t *__restrict__ depth,
+                                                            uint32_t *__restrict__ acc, float window) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint4 *my = list + wave * region_cap;
+    const uint32_t cnt = counts[wave];
+    for (uint32_t e = lane; e < cnt; e += 64) {
+        uint4 r = ld_stream(my + e);
+        float m = __uint_as_float(depth[r.x]);
+        if (!(__uint_as_float(r.y) > f_add(m, window))) acc_add(acc, (int)r.x, rgba[r.z]);
     }
 }
 
 void launch_accumulate(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const uint32_t *depth,
-                       uint32_t *acc, float window) {
+                       uint32_t *acc, float window, const uint4 *list, const uint32_t *counts) {
     uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) return;
-    uint64_t blocks = (n4 + kBlock - 1) / kBlock;
-    int grid = (int)(blocks < (uint64_t)kPtGrid ? blocks : (uint64_t)kPtGrid);
-    hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(kBlock), 0, s, (const float4 *)c.x, (const float4 *)c.y,
-                       (const float4 *)c.z, c.rgba, n4, P, W, H, depth, acc, window);
+    int grid = point_grid(n4);
+    if (list)
+        hipLaunchKernelGGL(k_accumulate_list, dim3(grid), dim3(kBlock), 0, s, list, counts, list_region_cap(c.n),
+                           c.rgba, depth, acc, window);
+    else
+        hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(kBlock), 0, s, (const float4 *)c.x, (const float4 *)c.y,
+                           (const float4 *)c.z, c.rgba, n4, P, W, H, depth, acc, window);
+}
+
+// read-only probe: the same loads and projection arithmetic as the point passes but no
+// frame-buffer traffic -- the streaming ceiling of this access pattern.
+__global__ __launch_bounds__(kBlock) void k_stream_probe(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
+                                                         const float4 *__restrict__ z4, uint64_t n4, Proj P, int W,
+                                                         int H, uint32_t *__restrict__ sink) {
+    const float fW = (float)W, fH = (float)H;
+    uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    uint32_t h = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+        Quad q = project_quad(x4, y4, z4, i, P, W, H, fW, fH);
+        h += (uint32_t)(q.pix[0] ^ q.pix[1] ^ q.pix[2] ^ q.pix[3]);
+    }
+    if (h == 0x12345678u) sink[0] = h;  // practically never; keeps the work alive
+}
+
+void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *sink) {
+    uint64_t n4 = (c.n + 3) / 4;
+    if (n4 == 0) return;
+    hipLaunchKernelGGL(k_stream_probe, dim3(point_grid(n4)), dim3(kBlock), 0, s, (const float4 *)c.x,
+                       (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, sink);
+}
+
+// =================================================================================
+// Tile-binned pipeline (the default frame form).
+//
+// Scattered device-scope atomics run at a few 10^10 per second on MI355X (they execute
+// at the memory side), which is what bounds the atomic forms above once the stream
+// itself runs at ~6 TB/s.  The binned form has NO global atomics on the frame buffers:
+//   T1 k_project_bin : stream the cloud once (12 B/pt), append every in-frustum point
+//                      as (pixel, depth bits, point index, tiled pixel index) to a list
+//                      private to the wave, count points per 32-row screen tile in LDS;
+//   T2 k_tile_scan   : exclusive scan of the tile histogram (one workgroup);
+//   T3 k_scatter     : counting-sort the entries by tile (LDS ranks, one contiguous
+//                      atomic claim per workgroup and tile);
+//   T4 k_tile_*      : one workgroup per tile keeps the tile's depth and accumulators in
+//                      LDS: ds_min (render.cu:81), barrier, window test + ds_add
+//                      (render.cu:106,125-128), barrier, resolve (render.cu:147-162) and
+//                      writes every pixel of the tile -- clear, both reference passes and
+//                      the resolve of one tile in one launch.
+// Results are identical to the atomic forms because min and integer sums commute.
+constexpr int kTileH = 32;
+
+struct TileGeom {
+    int tw_shift;  // log2(tile width): 5 (32x32) or 6 (64x32)
+    int tiles_x, tiles_y, ntiles;
+};
+
+__host__ __device__ inline TileGeom tile_geom(int W, int H) {
+    TileGeom g;
+    g.tw_shift = 5;
+    g.tiles_x = (W + 31) >> 5;
+    g.tiles_y = (H + kTileH - 1) / kTileH;
+    if (g.tiles_x * g.tiles_y > 4096) {  // keep the LDS histogram <= 16 KB (4K frames)
+        g.tw_shift = 6;
+        g.tiles_x = (W + 63) >> 6;
+    }
+    g.ntiles = g.tiles_x * g.tiles_y;
+    return g;
+}
+
+int tile_count(int W, int H) { return tile_geom(W, H).ntiles; }
+
+// projection that also reports the tile-major pixel index
+__device__ __forceinline__ bool project_tiled(const Proj &P, float x, float y, float z, int W, float fW, float fH,
+                                              const TileGeom &g, uint32_t &pix, uint32_t &dbits, uint32_t &tiled) {
+    float rx = f_add(fmaf(P.m[2], z, fmaf(P.m[1], y, f_mul(P.m[0], x))), P.m[3]);
+    float ry = f_add(fmaf(P.m[6], z, fmaf(P.m[5], y, f_mul(P.m[4], x))), P.m[7]);
+    float rz = f_add(fmaf(P.m[10], z, fmaf(P.m[9], y, f_mul(P.m[8], x))), P.m[11]);
+    float inv = 1.0f / rz;
+    float fu = rintf(f_mul(rx, inv));
+    float fv = rintf(f_mul(ry, inv));
+    bool ok = (rz > 0.0f) && (fu >= 0.0f) && (fu < fW) && (fv >= 0.0f) && (fv < fH);
+    int u = (int)fu, v = (int)fv;
+    pix = (uint32_t)(v * W + u);
+    dbits = __float_as_uint(rz);
+    uint32_t tile = (uint32_t)((v >> 5) * g.tiles_x + (u >> g.tw_shift));
+    uint32_t local = (uint32_t)(((v & 31) << g.tw_shift) | (u & ((1 << g.tw_shift) - 1)));
+    tiled = (tile << (g.tw_shift + 5)) | local;
+    return ok;
+}
+
+// T1 ------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
+                                                        const float4 *__restrict__ z4, uint64_t n4, Proj P, int W,
+                                                        int H, TileGeom g, uint4 *__restrict__ list,
+                                                        uint32_t *__restrict__ counts, uint64_t region_cap,
+                                                        uint32_t *__restrict__ tile_hist) {
+    extern __shared__ uint32_t s_hist[];
+    for (int t = threadIdx.x; t < g.ntiles; t += kBlock) s_hist[t] = 0;
+    __syncthreads();
+    const float fW = (float)W, fH = (float)H;
+    const uint64_t gtid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const int lane = threadIdx.x & 63;
+    const int tshift = g.tw_shift + 5;
+    uint4 *my = list + (gtid >> 6) * region_cap;
+    uint32_t fill = 0;
+    for (uint64_t i = gtid; i < n4; i += stride) {
+        float4 X = ld_stream(x4 + i), Y = ld_stream(y4 + i), Z = ld_stream(z4 + i);
+        const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t pix, db, tiled;
+            bool in = project_tiled(P, xs[k], ys[k], zs[k], W, fW, fH, g, pix, db, tiled);
+            unsigned long long m = __ballot(in);
+            if (m == 0ull) continue;
+            if (in) {
+                uint32_t pos = fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                my[pos] = make_uint4(pix, db, (uint32_t)(4 * i + k), tiled);
+                atomicAdd(&s_hist[tiled >> tshift], 1u);
+            }
+            fill += (uint32_t)__popcll(m);
+        }
+    }
+    if (lane == 0) counts[gtid >> 6] = fill;
+    __syncthreads();
+    for (int t = threadIdx.x; t < g.ntiles; t += kBlock) {
+        uint32_t c = s_hist[t];
+        if (c) atomicAdd(&tile_hist[t], c);
+    }
+}
+
+// T2: exclusive scan of the histogram -> tile_start[0..ntiles], cursor[] = start, and the
+// histogram is re-zeroed for the next frame.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *__restrict__ tile_hist, uint32_t *__restrict__ tile_start,
+                                                    uint32_t *__restrict__ cursor, int ntiles) {
+    __shared__ uint32_t s_part[1024];
+    const int per = (ntiles + 1023) / 1024;
+    const int lo = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (int k = 0; k < per; ++k)
+        if (lo + k < ntiles) sum += tile_hist[lo + k];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+        uint32_t v = (threadIdx.x >= (unsigned)off) ? s_part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[threadIdx.x] - sum;  // exclusive prefix of this thread's chunk
+    for (int k = 0; k < per; ++k)
+        if (lo + k < ntiles) {
+            uint32_t c = tile_hist[lo + k];
+            tile_start[lo + k] = run;
+            cursor[lo + k] = run;
+            tile_hist[lo + k] = 0;
+            run += c;
+        }
+    if (threadIdx.x == 1023) tile_start[ntiles] = s_part[1023];
+}
+
+// T3: counting sort by tile.  Workgroup b re-reads the four wave lists that workgroup b
+// of T1 wrote (same grid), ranks entries per tile in LDS, claims a contiguous range per
+// tile with one returning atomic, then writes the entries to their tile's segment.
+__global__ __launch_bounds__(kBlock) void k_scatter(const uint4 *__restrict__ list, const uint32_t *__restrict__ counts,
+                                                    uint64_t region_cap, int ntiles, int tshift,
+                                                    uint32_t *__restrict__ cursor, uint4 *__restrict__ binned) {
+    extern __shared__ uint32_t s_cnt[];  // [ntiles] counts, then bases
+    for (int t = threadIdx.x; t < ntiles; t += kBlock) s_cnt[t] = 0;
+    __syncthreads();
+    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint4 *my = list + wave * region_cap;
+    const uint32_t cnt = counts[wave];
+    for (uint32_t e = lane; e < cnt; e += 64) atomicAdd(&s_cnt[my[e].w >> tshift], 1u);
+    __syncthreads();
+    for (int t = threadIdx.x; t < ntiles; t += kBlock) {
+        uint32_t c = s_cnt[t];
+        s_cnt[t] = c ? atomicAdd(&cursor[t], c) : 0u;  // now the base of this workgroup's run
+    }
+    __syncthreads();
+    for (uint32_t e = lane; e < cnt; e += 64) {
+        uint4 r = my[e];
+        uint32_t pos = atomicAdd(&s_cnt[r.w >> tshift], 1u);
+        binned[pos] = r;
+    }
+}
+
+// T4: per-tile LDS z-buffer.  MODE 0 = whole frame (min + accumulate + resolve, writes
+// depth / image / optionally the accumulators); MODE 1 = min only (depth = min(depth,
+// tile min): the phase call before the multi-GPU MIN all-reduce); MODE 2 = accumulate
+// only against the depth buffer in memory (acc += tile sums).
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_tile(const uint4 *__restrict__ binned,
+                                                 const uint32_t *__restrict__ tile_start,
+                                                 const uint32_t *__restrict__ rgba, TileGeom g, int W, int H,
+                                                 float window, uint32_t *__restrict__ depth,
+                                                 uint32_t *__restrict__ acc, uint8_t *__restrict__ img, int write_acc) {
+    extern __shared__ uint32_t s_mem[];
+    const int tpix = 32 << g.tw_shift;  // pixels per tile
+    uint32_t *s_depth = s_mem;          // [tpix]
+    uint32_t *s_acc = s_mem + tpix;     // [4 * tpix]
+    const int tile = blockIdx.x;
+    const int tx0 = (tile % g.tiles_x) << g.tw_shift, ty0 = (tile / g.tiles_x) * kTileH;
+    const int tw = 1 << g.tw_shift, tmask = tpix - 1;
+    const uint32_t e0 = tile_start[tile], e1 = tile_start[tile + 1];
+
+    for (int p = threadIdx.x; p < tpix; p += kBlock) {
+        if (MODE == 2) {
+            int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
+            s_depth[p] = (x < W && y < H) ? depth[(size_t)y * W + x] : RTR_EMPTY;
+        } else {
+            s_depth[p] = RTR_EMPTY;
+        }
+    }
+    if (MODE != 1)
+        for (int p = threadIdx.x; p < 4 * tpix; p += kBlock) s_acc[p] = 0;
+    __syncthreads();
+    if (MODE != 2) {
+        for (uint32_t e = e0 + threadIdx.x; e < e1; e += kBlock) {
+            uint4 r = binned[e];
+            atomicMin(&s_depth[r.w & tmask], r.y);  // render.cu:81
+        }
+        __syncthreads();
+    }
+    if (MODE != 1) {
+        for (uint32_t e = e0 + threadIdx.x; e < e1; e += kBlock) {
+            uint4 r = binned[e];
+            int p = r.w & tmask;
+            float m = __uint_as_float(s_depth[p]);
+            if (!(__uint_as_float(r.y) > f_add(m, window))) {  // render.cu:106
+                uint32_t c = rgba[r.z];
+                atomicAdd(&s_acc[4 * p + 0], c & 0xFFu);  // render.cu:125-128
+                atomicAdd(&s_acc[4 * p + 1], (c >> 8) & 0xFFu);
+                atomicAdd(&s_acc[4 * p + 2], (c >> 16) & 0xFFu);
+                atomicAdd(&s_acc[4 * p + 3], 1u);
+            }
+        }
+        __syncthreads();
+    }
+    // write-out: one thread per pixel, rows of the tile are contiguous in memory
+    for (int p = threadIdx.x; p < tpix; p += kBlock) {
+        int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
+        if (x >= W || y >= H) continue;
+        size_t gp = (size_t)y * W + x;
+        if (MODE == 0) {
+            depth[gp] = s_depth[p];
+        } else if (MODE == 1) {
+            uint32_t old = depth[gp], v = s_depth[p];
+            if (v < old) depth[gp] = v;
+        }
+        if (MODE != 1) {
+            uint32_t a0 = s_acc[4 * p], a1 = s_acc[4 * p + 1], a2 = s_acc[4 * p + 2], c = s_acc[4 * p + 3];
+            if (MODE == 2) {
+                uint4 o = reinterpret_cast<uint4 *>(acc)[gp];
+                reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(o.x + a0, o.y + a1, o.z + a2, o.w + c);
+            } else {
+                if (write_acc) reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(a0, a1, a2, c);
+                img[3 * gp + 0] = c ? (uint8_t)(a0 / c) : 0;  // render.cu:147-162
+                img[3 * gp + 1] = c ? (uint8_t)(a1 / c) : 0;
+                img[3 * gp + 2] = c ? (uint8_t)(a2 / c) : 0;
+            }
+        }
+    }
+}
+
+void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint4 *list, uint32_t *counts,
+                        uint32_t *tile_hist) {
+    TileGeom g = tile_geom(W, H);
+    uint64_t n4 = (c.n + 3) / 4;
+    if (n4 == 0) return;
+    hipLaunchKernelGGL(k_project_bin, dim3(point_grid(n4)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s,
+                       (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, g, list, counts,
+                       list_region_cap(c.n), tile_hist);
+}
+
+void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const uint4 *list, const uint32_t *counts,
+                     uint4 *binned, uint32_t *tile_hist, uint32_t *tile_start, uint32_t *cursor) {
+    TileGeom g = tile_geom(W, H);
+    uint64_t n4 = (c.n + 3) / 4;
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, tile_hist, tile_start, cursor, g.ntiles);
+    if (n4 == 0) return;
+    hipLaunchKernelGGL(k_scatter, dim3(point_grid(n4)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s, list, counts,
+                       list_region_cap(c.n), g.ntiles, g.tw_shift + 5, cursor, binned);
+}
+
+void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const uint4 *binned,
+                 const uint32_t *tile_start, float window, uint32_t *depth, uint32_t *acc, uint8_t *img,
+                 int write_acc) {
+    TileGeom g = tile_geom(W, H);
+    size_t tpix = (size_t)32 << g.tw_shift;
+    size_t lds = (mode == 1 ? tpix : 5 * tpix) * sizeof(uint32_t);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_tile<0>, dim3(g.ntiles), dim3(kBlock), lds, s, binned, tile_start, c.rgba, g, W, H, window,
+                           depth, acc, img, write_acc);
+    else if (mode == 1)
+        hipLaunchKernelGGL(k_tile<1>, dim3(g.ntiles), dim3(kBlock), lds, s, binned, tile_start, c.rgba, g, W, H, window,
+                           depth, acc, img, 0);
+    else
+        hipLaunchKernelGGL(k_tile<2>, dim3(g.ntiles), dim3(kBlock), lds, s, binned, tile_start, c.rgba, g, W, H, window,
+                           depth, acc, img, 1);
 }
 
 // ---------------------------------------------------------------------------------
@@ -431,7 +824,7 @@ __device__ void room_shell_point(uint64_t seed, uint64_t i, uint64_t total, floa
             vx = copysignf(f_sub(1.0f, ab), a);
             vy = copysignf(f_sub(1.0f, aa), bb);
         }
-        float len = __fsqrt_rn(fmaf(vz, vz, fmaf(vy, vy, f_mul(vx, vx))));
+        float len = __builtin_sqrtf(fmaf(vz, vz, fmaf(vy, vy, f_mul(vx, vx))));
         float k = 0.5f / len;
         px = fmaf(vx, k, cxs);
         py = fmaf(vy, k, cys);

@@ -74,6 +74,13 @@ class Projector:
             setattr(p, k, v)
         self._chk(self._lib.rtr_set_params(self._ctx, C.byref(p)))
 
+    def set_option(self, key, value):
+        self._chk(self._lib.rtr_set_option(self._ctx, key.encode(), int(value)))
+
+    def stream_probe(self, P):
+        P = self._P(P)
+        self._chk(self._lib.rtr_stream_probe(self._ctx, _vp(P)))
+
     # -- cloud
     def upload_points(self, xyz, rgb):
         """xyz: float32 [n,3|4] (the reference's float4 (x,y,z,1) or tight xyz);

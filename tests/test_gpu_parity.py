@@ -17,8 +17,11 @@ def _check_frame(pkg, orc, projector, xyzw, rgba, P, W, H, filtered=True):
     img, depth = projector.project(P)
     ref = orc.project(xyzw, rgba, P, W, H)
     assert np.array_equal(depth.view(np.uint32), ref["depth_bits"])
-    assert np.array_equal(projector.download(pkg._lib.BUF_ACCUM), ref["acc"])
     assert np.array_equal(img, ref["img"])
+    projector.set_option("keep_accum", 1)
+    projector.render(P)
+    assert np.array_equal(projector.download(pkg._lib.BUF_ACCUM), ref["acc"])
+    projector.set_option("keep_accum", 0)
     assert np.max(np.abs(depth[ref["depth_bits"] != orc.EMPTY_DEPTH] -
                          ref["depth_bits"].view(np.float32)[ref["depth_bits"] != orc.EMPTY_DEPTH]), initial=0) <= 1e-5
     if filtered:
@@ -32,9 +35,18 @@ def _check_frame(pkg, orc, projector, xyzw, rgba, P, W, H, filtered=True):
     return ref
 
 
+@pytest.fixture(params=[2, 1, 0], ids=["tile", "compact", "two-pass"])
+def mode(request, projector):
+    projector.set_option("mode", request.param)
+    projector.set_option("keep_accum", 1)
+    yield request.param
+    projector.set_option("mode", 2)
+    projector.set_option("keep_accum", 0)
+
+
 @pytest.mark.parametrize("scene", ["uniform_box", "room_shell"])
 @pytest.mark.parametrize("W,H", [(640, 480), (1920, 1080), (64, 48)])
-def test_scene_frame_parity(pkg, orc, projector, scene, W, H):
+def test_scene_frame_parity(pkg, orc, projector, mode, scene, W, H):
     n = 200_000
     xyzw, rgba = orc.generate(scene, 0xC0FFEE01, 0, n, n)
     for k in (0, 137, 500):
@@ -43,12 +55,12 @@ def test_scene_frame_parity(pkg, orc, projector, scene, W, H):
 
 
 @pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 255, 257, 1023, 4099])
-def test_ragged_point_counts(pkg, orc, projector, n):
+def test_ragged_point_counts(pkg, orc, projector, mode, n):
     xyzw, rgba = random_cloud(n, seed=n + 1)
     _check_frame(pkg, orc, projector, xyzw, rgba, pkg.orbit_projection(10, 64, 48), 64, 48)
 
 
-def test_kat_points(pkg, orc, projector):
+def test_kat_points(pkg, orc, projector, mode):
     P = kat_P(orc)
     pts = [(0, 0, 2), (0, 0, 0), (0, 0, -1), (0, 0, 1e-30), (-0.32, 0, 1.0), (-0.325, 0, 1.0), (0.315, 0, 1.0),
            (0.0, 0.0, 1.0), (0.0, 0.0, 1.01), (0.0, 0.0, 1.03)]
@@ -57,7 +69,7 @@ def test_kat_points(pkg, orc, projector):
     _check_frame(pkg, orc, projector, xyzw, rgba, P, 64, 48)
 
 
-def test_collisions_one_pixel(pkg, orc, projector):
+def test_collisions_one_pixel(pkg, orc, projector, mode):
     """300 identical points in one pixel plus a far crowd behind them (atomic contention)."""
     P = kat_P(orc)
     pts = [(0, 0, 2.0)] * 300 + [(0, 0, 2.015)] * 200 + [(0, 0, 2.5)] * 100
@@ -67,7 +79,7 @@ def test_collisions_one_pixel(pkg, orc, projector):
     assert ref["acc"][24, 32, 3] == 500
 
 
-def test_shuffle_and_shard_invariance(pkg, orc, projector):
+def test_shuffle_and_shard_invariance(pkg, orc, projector, mode):
     n, W, H = 100_000, 640, 480
     xyzw, rgba = orc.generate("room_shell", 7, 0, n, n)
     P = pkg.orbit_projection(42, W, H)
@@ -91,7 +103,7 @@ def test_generator_matches_oracle(pkg, orc, projector):
             assert np.array_equal(rgba, rc), scene
 
 
-def test_phase_calls_equal_whole_frame(pkg, orc, projector):
+def test_phase_calls_equal_whole_frame(pkg, orc, projector, mode):
     n, W, H = 50_000, 320, 240
     xyzw, rgba = orc.generate("uniform_box", 11, 0, n, n)
     P = pkg.orbit_projection(5, W, H)
