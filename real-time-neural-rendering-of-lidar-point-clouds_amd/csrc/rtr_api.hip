@@ -33,7 +33,8 @@ struct rtr_ctx {
     // frame buffers
     int W = 0, H = 0;
     uint32_t *depth = nullptr, *acc = nullptr, *minmax = nullptr;
-    uint8_t *img = nullptr, *mask = nullptr, *grad = nullptr;
+    uint8_t *img = nullptr, *mask = nullptr;
+    uint32_t *part_min = nullptr, *part_max = nullptr;  // per-tile min / max partials of the prefilter
     uint16_t *tensor = nullptr;
     rtr::FilterLevels lv{};
     int lv_levels = 0;  // levels the pyramid was allocated for
@@ -98,7 +99,7 @@ void dfree(T *&p) {
 
 void free_frame(rtr_ctx *c) {
     c->list_valid = false;
-    dfree(c->depth); dfree(c->acc); dfree(c->img); dfree(c->mask); dfree(c->grad); dfree(c->tensor);
+    dfree(c->depth); dfree(c->acc); dfree(c->img); dfree(c->mask); dfree(c->part_min); dfree(c->part_max); dfree(c->tensor);
     for (int i = 1; i <= 8; ++i) dfree(c->lv.lv[i]);
     dfree(c->tile_hist); dfree(c->tile_start); dfree(c->cursor);
     c->tiles_n = 0;
@@ -466,7 +467,9 @@ int rtr_set_resolution(rtr_ctx *c, int W, int H) {
     HIP_TRY(c, hipMalloc((void **)&c->acc, npix * 16));
     HIP_TRY(c, hipMalloc((void **)&c->img, (npix * 3 + 15) & ~(size_t)15));
     HIP_TRY(c, hipMalloc((void **)&c->mask, npix));
-    HIP_TRY(c, hipMalloc((void **)&c->grad, npix));
+    size_t nparts = (size_t)((W + 31) / 32) * ((H + 31) / 32);
+    HIP_TRY(c, hipMalloc((void **)&c->part_min, nparts * 4));
+    HIP_TRY(c, hipMalloc((void **)&c->part_max, nparts * 4));
     HIP_TRY(c, hipMalloc((void **)&c->tensor, npix * 5 * sizeof(uint16_t)));
     c->W = W; c->H = H;
     return RTR_OK;
@@ -567,7 +570,8 @@ int rtr_filter(rtr_ctx *c) {
     if (int rc = ensure_pyramid(c)) return rc;
     {
         Timed t(c, RTR_K_FILTER);
-        rtr::launch_filter(c->stream, c->lv, c->depth, c->img, c->mask, c->grad, c->tensor, c->minmax, c->W, c->H,
+        rtr::launch_filter(c->stream, c->lv, c->depth, c->img, c->mask, c->tensor, c->minmax, c->part_min, c->part_max,
+                           c->W, c->H,
                            c->prm.filter_strength, c->prm.gradient_threshold);
     }
     return launch_check(c, "filter");

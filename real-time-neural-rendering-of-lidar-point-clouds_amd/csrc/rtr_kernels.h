@@ -47,7 +47,8 @@ void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const ui
 void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *sink);
 void launch_resolve(hipStream_t s, const uint32_t *acc, uint8_t *img, size_t npix);
 void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, uint8_t *img, uint8_t *mask,
-                   uint8_t *grad, uint16_t *tensor, uint32_t *minmax, int W, int H, float strength, float thr);
+                   uint16_t *tensor, uint32_t *minmax, uint32_t *part_min, uint32_t *part_max, int W, int H,
+                   float strength, float thr);
 void launch_generate(hipStream_t s, int scene, uint64_t seed, uint64_t first, uint64_t count, uint64_t total,
                      float *x, float *y, float *z, uint32_t *rgba);
 void launch_aos_to_soa(hipStream_t s, const uint8_t *xyz, size_t xyz_stride, const uint8_t *rgb, size_t rgb_stride,

@@ -574,9 +574,104 @@ void launch_resolve(hipStream_t s, const uint32_t *acc, uint8_t *img, size_t npi
 }
 
 // ---------------------------------------------------------------------------------
-// depth-heuristic prefilter (project_cloud.cu:28-187)
+// depth-heuristic prefilter (project_cloud.cu:28-187, launch sequence :331-392).
+// The reference runs ~20 dependent launches, 12 malloc/free and ~20 device syncs per
+// frame; here it is 5 launches on pre-allocated levels:
+//   F1 k_pyramid : all min-pool levels (A8) of a 32x32 depth tile through LDS + per-tile
+//                  min / max partials (A12)
+//   F2..F4 k_up  : per level: Laplacian of the parent (A9, recomputed per child), compare
+//                  (A10) and in-place bilinear fill of rejected pixels (A11)
+//   F5 k_final   : level-0 compare + removeMask + fp16 tensor (A13), four pixels a thread
+// Arithmetic is op-for-op that of oracle/rtr_oracle.c.
 
-// A8 reduce (project_cloud.cu:28-53): 2x2 min-pool; source row stride 2*w.
+__device__ __forceinline__ float min2(float a, float b) { return a < b ? a : b; }  // project_cloud.cu:46-49
+
+// F1.  A8 reduce (project_cloud.cu:28-53) for every level at once.  Level i pixel (x, y)
+// exists iff x < w[i], y < h[i] (dims halve with integer division), and then all four
+// children exist.  A12 (render.cu:168-240): min / max of the depth BIT PATTERNS over the
+// first n_eff pixels, sentinel skipped; per-tile partials, reduced by F2's workgroup 0.
+__global__ __launch_bounds__(kBlock) void k_pyramid(FilterLevels L, int tiles_x, uint32_t n_eff_rows,
+                                                    uint32_t *__restrict__ part_min, uint32_t *__restrict__ part_max) {
+    __shared__ float s1[256], s2[64], s3[16];
+    __shared__ uint32_t s_mm[8];
+    const int t = threadIdx.x;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    {
+        const int lx = t & 15, ly = t >> 4;
+        const int gx = tx * 16 + lx, gy = ty * 16 + ly;
+        float v = 0.0f;
+        if (L.levels >= 1 && gx < L.w[1] && gy < L.h[1]) {
+            const float *r0 = L.lv[0] + (size_t)(2 * gy) * L.w[0] + 2 * gx;
+            float2 a = *reinterpret_cast<const float2 *>(r0);
+            float2 b = *reinterpret_cast<const float2 *>(r0 + L.w[0]);
+            v = min2(min2(a.x, a.y), min2(b.x, b.y));
+            L.lv[1][(size_t)gy * L.w[1] + gx] = v;
+            if ((uint32_t)(2 * gy) < n_eff_rows) {  // n_eff_rows is even: both rows or none
+                const uint32_t q[4] = {__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(b.x),
+                                       __float_as_uint(b.y)};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (q[k] != RTR_EMPTY) {
+                        lo = q[k] < lo ? q[k] : lo;
+                        hi = q[k] > hi ? q[k] : hi;
+                    }
+            }
+        }
+        s1[t] = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t ol = __shfl_xor(lo, off, 64), oh = __shfl_xor(hi, off, 64);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    if ((t & 63) == 0) {
+        s_mm[t >> 6] = lo;
+        s_mm[4 + (t >> 6)] = hi;
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t a = s_mm[0], b = s_mm[4];
+        for (int k = 1; k < 4; ++k) {
+            a = s_mm[k] < a ? s_mm[k] : a;
+            b = s_mm[4 + k] > b ? s_mm[4 + k] : b;
+        }
+        part_min[blockIdx.x] = a;
+        part_max[blockIdx.x] = b;
+    }
+    if (L.levels >= 2 && t < 64) {
+        const int lx = t & 7, ly = t >> 3, gx = tx * 8 + lx, gy = ty * 8 + ly;
+        float v = 0.0f;
+        if (gx < L.w[2] && gy < L.h[2]) {
+            const float *c = s1 + (2 * ly) * 16 + 2 * lx;
+            v = min2(min2(c[0], c[1]), min2(c[16], c[17]));
+            L.lv[2][(size_t)gy * L.w[2] + gx] = v;
+        }
+        s2[t] = v;
+    }
+    __syncthreads();
+    if (L.levels >= 3 && t < 16) {
+        const int lx = t & 3, ly = t >> 2, gx = tx * 4 + lx, gy = ty * 4 + ly;
+        float v = 0.0f;
+        if (gx < L.w[3] && gy < L.h[3]) {
+            const float *c = s2 + (2 * ly) * 8 + 2 * lx;
+            v = min2(min2(c[0], c[1]), min2(c[8], c[9]));
+            L.lv[3][(size_t)gy * L.w[3] + gx] = v;
+        }
+        s3[t] = v;
+    }
+    __syncthreads();
+    if (L.levels >= 4 && t < 4) {
+        const int lx = t & 1, ly = t >> 1, gx = tx * 2 + lx, gy = ty * 2 + ly;
+        if (gx < L.w[4] && gy < L.h[4]) {
+            const float *c = s3 + (2 * ly) * 4 + 2 * lx;
+            L.lv[4][(size_t)gy * L.w[4] + gx] = min2(min2(c[0], c[1]), min2(c[4], c[5]));
+        }
+    }
+}
+
+// generic single-level reduce for pyramids deeper than 4 levels (levels 5..8)
 __global__ __launch_bounds__(kBlock) void k_reduce(const float *__restrict__ hi, float *__restrict__ lo, int w, int h) {
     int idx = blockIdx.x * kBlock + threadIdx.x;
     if (idx >= w * h) return;
@@ -584,67 +679,92 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const float *__restrict__ hi,
     const float2 *r0 = (const float2 *)(hi + (size_t)(2 * y) * (2 * w)) + x;
     const float2 *r1 = (const float2 *)(hi + (size_t)(2 * y + 1) * (2 * w)) + x;
     float2 a = *r0, b = *r1;
-    float l0 = a.x < a.y ? a.x : a.y;
-    float l1 = b.x < b.y ? b.x : b.y;
-    lo[idx] = l0 < l1 ? l0 : l1;
+    lo[idx] = min2(min2(a.x, a.y), min2(b.x, b.y));
 }
 
-// A9 laplacianKernel (project_cloud.cu:55-79): all nine taps, row-major, fmaf chain.
-__global__ __launch_bounds__(kBlock) void k_laplacian(const float *__restrict__ in, uint8_t *__restrict__ out, int w,
-                                                      int h, float thr) {
-    int idx = blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= w * h) return;
-    int x = idx % w, y = idx / w;
-    if (x == 0 || x == w - 1 || y == 0 || y == h - 1) {
-        out[idx] = 0;
-        return;
-    }
-    const float k[9] = {0.f, 1.f, 0.f, 1.f, -4.f, 1.f, 0.f, 1.f, 0.f};  // project_cloud.cu:26
+// A9 laplacianKernel (project_cloud.cu:55-79) for ONE low-res pixel: border -> 0, else the
+// nine-tap fmaf chain in row-major order (zero-weight corners included) compared with thr.
+__device__ __forceinline__ bool lap_flag(const float *__restrict__ lo, int x, int y, int w, int h, float thr) {
+    if (x == 0 || x == w - 1 || y == 0 || y == h - 1) return false;
+    const float *r = lo + (size_t)(y - 1) * w + (x - 1);
     float sum = 0.0f;
-#pragma unroll
-    for (int ky = -1; ky <= 1; ++ky)
-#pragma unroll
-        for (int kx = -1; kx <= 1; ++kx) sum = fmaf(in[(y + ky) * w + (x + kx)], k[(ky + 1) * 3 + (kx + 1)], sum);
-    out[idx] = (sum > thr) ? 255 : 0;
+    sum = fmaf(r[0], 0.0f, sum);
+    sum = fmaf(r[1], 1.0f, sum);
+    sum = fmaf(r[2], 0.0f, sum);
+    r += w;
+    sum = fmaf(r[0], 1.0f, sum);
+    sum = fmaf(r[1], -4.0f, sum);
+    sum = fmaf(r[2], 1.0f, sum);
+    r += w;
+    sum = fmaf(r[0], 0.0f, sum);
+    sum = fmaf(r[1], 1.0f, sum);
+    sum = fmaf(r[2], 0.0f, sum);
+    return sum > thr;
 }
 
 __device__ __forceinline__ float lo_px(const float *__restrict__ lo, int x, int y, int w, int h) {
-    return (x >= 0 && x < w && y >= 0 && y < h) ? lo[y * w + x] : -1.0f;  // project_cloud.cu:81-86
+    return (x >= 0 && x < w && y >= 0 && y < h) ? lo[(size_t)y * w + x] : -1.0f;  // project_cloud.cu:81-86
 }
 
-// A10 compareImgsKernel (project_cloud.cu:88-126)
-__global__ __launch_bounds__(kBlock) void k_compare(const float *__restrict__ lo, const float *__restrict__ hi,
-                                                    const uint8_t *__restrict__ grad, uint8_t *__restrict__ mask, int hw,
-                                                    int hh, float strength) {
-    int idx = blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= hw * hh) return;
-    int x = idx % hw, y = idx / hw;
-    float cur = hi[idx];
-    if ((double)cur >= 3.4028e38) {  // MAX_FLOAT, project_cloud.cu:21,97
-        mask[idx] = 0;
-        return;
-    }
-    int lw = hw / 2, lh = hh / 2, lx = x / 2, ly = y / 2;
-    bool keep = false;
-    if (grad[ly * lw + lx] > 0) {
+// A10 compareImgsKernel (project_cloud.cu:88-126) for one hi-res pixel
+__device__ __forceinline__ bool keep_px(const float *__restrict__ lo, float cur, int x, int y, int lw, int lh,
+                                        float strength, float thr) {
+    if ((double)cur >= 3.4028e38) return false;  // MAX_FLOAT, project_cloud.cu:21,97
+    const int lx = x >> 1, ly = y >> 1;
+    if (lap_flag(lo, lx, ly, lw, lh, thr)) {
+        bool keep = false;
 #pragma unroll
-        for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) keep = keep || (cur <= f_mul(lo_px(lo, lx + dx, ly + dy, lw, lh), strength));
-    } else {
-        keep = cur <= f_mul(lo_px(lo, lx, ly, lw, lh), strength);
+            for (int dx = -1; dx <= 1; ++dx) keep = keep || (cur <= f_mul(lo_px(lo, lx + dx, ly + dy, lw, lh), strength));
+        return keep;
     }
-    mask[idx] = keep ? 255 : 0;
+    return cur <= f_mul(lo_px(lo, lx, ly, lw, lh), strength);
 }
 
-// A11 resizeKernel (project_cloud.cu:128-161): in-place bilinear x2 where mask == 0.
-__global__ __launch_bounds__(kBlock) void k_resize(const float *__restrict__ lo, float *__restrict__ hi,
-                                                   const uint8_t *__restrict__ mask, int ow, int oh) {
+// F2..F4: level i (lo, lw x lh) against level i-1 (hi, 2lw x 2lh): compare, and where the
+// pixel is rejected or empty write the bilinear x2 up-sample of lo in place (A11,
+// project_cloud.cu:128-161).  Workgroup 0 of the first call also folds the min / max
+// partials of F1 into minmax[2].
+__global__ __launch_bounds__(kBlock) void k_up(const float *__restrict__ lo, float *__restrict__ hi, int lw, int lh,
+                                               float strength, float thr, const uint32_t *__restrict__ part_min,
+                                               const uint32_t *__restrict__ part_max, int nparts,
+                                               uint32_t *__restrict__ minmax) {
+    if (part_min != nullptr && blockIdx.x == 0) {
+        __shared__ uint32_t s_mm[8];
+        uint32_t a = 0xFFFFFFFFu, b = 0u;
+        for (int k = threadIdx.x; k < nparts; k += kBlock) {
+            uint32_t pa = part_min[k], pb = part_max[k];
+            a = pa < a ? pa : a;
+            b = pb > b ? pb : b;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            uint32_t oa = __shfl_xor(a, off, 64), ob = __shfl_xor(b, off, 64);
+            a = oa < a ? oa : a;
+            b = ob > b ? ob : b;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            s_mm[threadIdx.x >> 6] = a;
+            s_mm[4 + (threadIdx.x >> 6)] = b;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < 4; ++k) {
+                a = s_mm[k] < a ? s_mm[k] : a;
+                b = s_mm[4 + k] > b ? s_mm[4 + k] : b;
+            }
+            a = s_mm[0] < a ? s_mm[0] : a;
+            b = s_mm[4] > b ? s_mm[4] : b;
+            minmax[0] = a;
+            minmax[1] = b;
+        }
+    }
+    const int ow = 2 * lw, oh = 2 * lh;
     int idx = blockIdx.x * kBlock + threadIdx.x;
     if (idx >= ow * oh) return;
-    if (mask[idx] > 0) return;
     int x = idx % ow, y = idx / ow;
-    int lw = ow / 2, lh = oh / 2;
+    if (keep_px(lo, hi[idx], x, y, lw, lh, strength, thr)) return;
     float inX = f_sub(f_add((float)x, 0.5f) / 2.0f, 0.5f);
     float inY = f_sub(f_add((float)y, 0.5f) / 2.0f, 0.5f);
     int x0 = (int)floorf(inX), x1 = x0 + 1, y0 = (int)floorf(inY), y1 = y0 + 1;
@@ -653,113 +773,106 @@ __global__ __launch_bounds__(kBlock) void k_resize(const float *__restrict__ lo,
     y0 = y0 < 0 ? 0 : (y0 >= lh ? lh - 1 : y0);
     y1 = y1 < 0 ? 0 : (y1 >= lh ? lh - 1 : y1);
     float wx = f_sub(inX, (float)x0), wy = f_sub(inY, (float)y0);
-    float v0 = fmaf(wx, lo[y0 * lw + x1], f_mul(f_sub(1.0f, wx), lo[y0 * lw + x0]));
-    float v1 = fmaf(wx, lo[y1 * lw + x1], f_mul(f_sub(1.0f, wx), lo[y1 * lw + x0]));
+    float v0 = fmaf(wx, lo[(size_t)y0 * lw + x1], f_mul(f_sub(1.0f, wx), lo[(size_t)y0 * lw + x0]));
+    float v1 = fmaf(wx, lo[(size_t)y1 * lw + x1], f_mul(f_sub(1.0f, wx), lo[(size_t)y1 * lw + x0]));
     hi[idx] = fmaf(wy, v1, f_mul(f_sub(1.0f, wy), v0));
 }
 
-// A12 (render.cu:168-240): min / max of the depth bit patterns, sentinel skipped.
-// wave64 shuffle reduction, one atomic pair per wave; minmax[] pre-set to {~0, 0}.
-__global__ __launch_bounds__(kBlock) void k_minmax(const uint32_t *__restrict__ d, size_t n,
-                                                   uint32_t *__restrict__ minmax) {
-    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-    size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        uint32_t v = d[i];
-        if (v != RTR_EMPTY) {
-            lo = v < lo ? v : lo;
-            hi = v > hi ? v : hi;
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        uint32_t ol = __shfl_xor(lo, off, 64), oh = __shfl_xor(hi, off, 64);
-        lo = ol < lo ? ol : lo;
-        hi = oh > hi ? oh : hi;
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (lo != 0xFFFFFFFFu) atomicMin(&minmax[0], lo);
-        if (hi != 0u) atomicMax(&minmax[1], hi);
-    }
-}
-
-__global__ void k_minmax_init(uint32_t *minmax) {
-    minmax[0] = 0xFFFFFFFFu;
-    minmax[1] = 0u;
-}
-
-__device__ __forceinline__ uint16_t to_half_bits(float f) {
+__device__ __forceinline__ uint32_t to_half_bits(float f) {
     if (f != f) return 0x7E00u;  // canonical NaN (oracle does the same)
     return __half_as_ushort(__float2half_rn(f));
 }
 __device__ __forceinline__ float half_round(float f) { return __half2float(__float2half_rn(f)); }
 
-// A13 removeMask (project_cloud.cu:163-187) over ALL W*H pixels, tensor plane stride
-// W*H (the reference strides by W*H_eff: quirk Q3).  Rows >= H_eff never saw the
-// pyramid test: their mask is "non-empty".
-__global__ __launch_bounds__(kBlock) void k_remove_mask(float *__restrict__ depth, uint8_t *__restrict__ img,
-                                                        uint8_t *__restrict__ mask, uint16_t *__restrict__ tensor,
-                                                        const uint32_t *__restrict__ minmax, size_t npix,
-                                                        size_t n_eff) {
-    size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+// F5: level-0 compare (A10) + removeMask (A13, project_cloud.cu:163-187) over ALL W*H
+// pixels, four horizontally adjacent pixels per thread (W % 16 == 0), tensor plane stride
+// W*H (the reference strides by W*H_eff: quirk Q3).  Rows >= H_eff never saw the pyramid
+// test: their mask is "non-empty".
+__global__ __launch_bounds__(kBlock) void k_final(const float *__restrict__ l1, float *__restrict__ depth,
+                                                  uint8_t *__restrict__ img, uint8_t *__restrict__ mask,
+                                                  uint16_t *__restrict__ tensor, const uint32_t *__restrict__ minmax,
+                                                  int W, int H, int lw, int lh, float strength, float thr) {
+    const size_t npix = (size_t)W * H, q = (size_t)blockIdx.x * kBlock + threadIdx.x, idx = q * 4;
     if (idx >= npix) return;
-    float d = depth[idx];
-    uint8_t m;
-    if (idx < n_eff) {
-        m = mask[idx];
-    } else {
-        m = ((double)d >= 3.4028e38) ? 0 : 255;
-        mask[idx] = m;
-    }
-    if (m == 0) {
-        depth[idx] = -1.0f;
-        img[3 * idx + 0] = 0;
-        img[3 * idx + 1] = 0;
-        img[3 * idx + 2] = 0;
-        tensor[0 * npix + idx] = 0;
-        tensor[1 * npix + idx] = 0;
-        tensor[2 * npix + idx] = 0;
-        tensor[3 * npix + idx] = 0;
-        tensor[4 * npix + idx] = 0xBC00u;
-        return;
-    }
-    float mn = __uint_as_float(minmax[0]), mx = __uint_as_float(minmax[1]);
-    float range = f_sub(mx, mn);
+    const int x = (int)(idx % W), y = (int)(idx / W);
+    const float mn = __uint_as_float(minmax[0]), range = f_sub(__uint_as_float(minmax[1]), mn);
+    float4 d4 = *reinterpret_cast<float4 *>(depth + idx);
+    float d[4] = {d4.x, d4.y, d4.z, d4.w};
+    uint32_t *ip = reinterpret_cast<uint32_t *>(img + idx * 3);
+    uint32_t iw[3] = {ip[0], ip[1], ip[2]};
+    uint32_t mbits = 0;
+    uint32_t th[5][4];
+    const bool in_domain = y < 2 * lh;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) tensor[k * npix + idx] = to_half_bits(half_round((float)img[3 * idx + k]) / 255.0f);
-    tensor[3 * npix + idx] = to_half_bits(half_round((float)m) / 255.0f);
-    tensor[4 * npix + idx] = to_half_bits(half_round(f_sub(d, mn)) / range);
-}
-
-// A14 applyDepthFilter (project_cloud.cu:331-392): same launch sequence, but on
-// pre-allocated levels and without any host synchronisation or malloc per frame.
-void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, uint8_t *img, uint8_t *mask,
-                   uint8_t *grad, uint16_t *tensor, uint32_t *minmax, int W, int H, float strength, float thr) {
-    auto blocks = [](size_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); };
-    const int nl = L.levels;
-    for (int i = 1; i <= nl; ++i)
-        hipLaunchKernelGGL(k_reduce, blocks((size_t)L.w[i] * L.h[i]), dim3(kBlock), 0, s, L.lv[i - 1], L.lv[i], L.w[i],
-                           L.h[i]);
-    int cw = L.w[nl], ch = L.h[nl];
-    size_t npix = (size_t)W * H;
-    for (int i = nl; i >= 1; --i) {
-        hipLaunchKernelGGL(k_laplacian, blocks((size_t)cw * ch), dim3(kBlock), 0, s, L.lv[i], grad, cw, ch, thr);
-        cw *= 2;
-        ch *= 2;
-        hipLaunchKernelGGL(k_compare, blocks((size_t)cw * ch), dim3(kBlock), 0, s, L.lv[i], L.lv[i - 1], grad, mask, cw,
-                           ch, strength);
-        if (i == 1) {
-            size_t n_eff = (size_t)cw * ch;
-            hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, s, minmax);
-            int g = (int)((n_eff + kBlock - 1) / kBlock);
-            if (g > 1024) g = 1024;
-            hipLaunchKernelGGL(k_minmax, dim3(g), dim3(kBlock), 0, s, depth_bits, n_eff, minmax);
-            hipLaunchKernelGGL(k_remove_mask, blocks(npix), dim3(kBlock), 0, s, (float *)depth_bits, img, mask, tensor,
-                               minmax, npix, n_eff);
+    for (int k = 0; k < 4; ++k) {
+        bool keep = in_domain ? keep_px(l1, d[k], x + k, y, lw, lh, strength, thr) : !((double)d[k] >= 3.4028e38);
+        if (!keep) {
+            d[k] = -1.0f;
+            th[0][k] = th[1][k] = th[2][k] = th[3][k] = 0;
+            th[4][k] = 0xBC00u;
         } else {
-            hipLaunchKernelGGL(k_resize, blocks((size_t)cw * ch), dim3(kBlock), 0, s, L.lv[i], L.lv[i - 1], mask, cw, ch);
+            mbits |= 0xFFu << (8 * k);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                int byte = 3 * k + c;
+                float v = (float)((iw[byte >> 2] >> (8 * (byte & 3))) & 0xFFu);
+                th[c][k] = to_half_bits(half_round(v) / 255.0f);
+            }
+            th[3][k] = 0x3C00u;  // half(float(half(255)) / 255.0f)
+            th[4][k] = to_half_bits(half_round(f_sub(d[k], mn)) / range);
         }
     }
+    // zero the colour bytes of rejected pixels
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (!((mbits >> (8 * k)) & 1u)) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                int byte = 3 * k + c;
+                iw[byte >> 2] &= ~(0xFFu << (8 * (byte & 3)));
+            }
+        }
+    *reinterpret_cast<float4 *>(depth + idx) = make_float4(d[0], d[1], d[2], d[3]);
+    ip[0] = iw[0];
+    ip[1] = iw[1];
+    ip[2] = iw[2];
+    *reinterpret_cast<uint32_t *>(mask + idx) = mbits;
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+        *reinterpret_cast<uint2 *>(tensor + (size_t)c * npix + idx) =
+            make_uint2(th[c][0] | (th[c][1] << 16), th[c][2] | (th[c][3] << 16));
+}
+
+// A14 applyDepthFilter (project_cloud.cu:331-392)
+void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, uint8_t *img, uint8_t *mask,
+                   uint16_t *tensor, uint32_t *minmax, uint32_t *part_min, uint32_t *part_max, int W, int H,
+                   float strength, float thr) {
+    auto blocks = [](size_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); };
+    const int nl = L.levels;
+    const int h_eff = (H >> nl) << nl;
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + 31) / 32, nparts = tiles_x * tiles_y;
+    FilterLevels L4 = L;
+    if (L4.levels > 4) L4.levels = 4;
+    hipLaunchKernelGGL(k_pyramid, dim3(nparts), dim3(kBlock), 0, s, L4, tiles_x, (uint32_t)h_eff, part_min, part_max);
+    for (int i = 5; i <= nl; ++i)
+        hipLaunchKernelGGL(k_reduce, blocks((size_t)L.w[i] * L.h[i]), dim3(kBlock), 0, s, L.lv[i - 1], L.lv[i], L.w[i],
+                           L.h[i]);
+    int cw = L.w[nl], ch = L.h[nl];  // the reference doubles the TRUNCATED dims (project_cloud.cu:360-361)
+    bool first = true;
+    for (int i = nl; i >= 2; --i) {
+        hipLaunchKernelGGL(k_up, blocks((size_t)4 * cw * ch), dim3(kBlock), 0, s, L.lv[i], L.lv[i - 1], cw, ch, strength,
+                           thr, first ? part_min : nullptr, first ? part_max : nullptr, nparts, minmax);
+        first = false;
+        cw *= 2;
+        ch *= 2;
+    }
+    if (first) {  // levels == 1: nothing folded the partials yet
+        hipLaunchKernelGGL(k_up, dim3(1), dim3(kBlock), 0, s, L.lv[1], L.lv[0], 0, 0, strength, thr, part_min, part_max,
+                           nparts, minmax);
+    }
+    size_t quads = ((size_t)W * H + 3) / 4;
+    hipLaunchKernelGGL(k_final, blocks(quads), dim3(kBlock), 0, s, L.lv[1], (float *)depth_bits, img, mask, tensor,
+                       minmax, W, H, cw, ch, strength, thr);
 }
 
 // ---------------------------------------------------------------------------------
