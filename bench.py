@@ -48,10 +48,20 @@ def parse():
     return ap.parse_args()
 
 
+def host_threads():
+    """Threads for the CPU leg: the process's CPU share, capped at 16 (each thread owns a
+    private 1080p frame buffer; more threads only grow the merge)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
 def cpu_baseline(orc, pkg, args):
     """The oracle's multi-thread projector (kind 'port') on a bounded sample of the same
     workload: a cpu-points instance of the same scene, same resolution and trajectory."""
-    cores = os.cpu_count() or 1
+    cores = host_threads()
     n, W, H = args.cpu_points, args.width, args.height
     xyzw, rgba = orc.generate(args.scene, SEEDS["C3"], 0, n, n)
     mt = orc.MTProjector(W, H, cores)
@@ -117,7 +127,7 @@ def main():
         orc = entry.load_oracle()
         xyzw, rgba = orc.generate(args.scene, SEEDS["C3"], 0, total, total)
         img, depth = proj.project(poses[0])
-        ref = orc.MTProjector(W, H, os.cpu_count() or 1).project(xyzw, rgba, poses[0])
+        ref = orc.MTProjector(W, H, host_threads()).project(xyzw, rgba, poses[0])
         parity = bool(np.array_equal(depth.view(np.uint32), ref["depth_bits"]) and np.array_equal(img, ref["img"]))
         del xyzw, rgba
 

@@ -65,6 +65,9 @@ class HipLocal:
     def filter(self):
         self.p.filter()
 
+    def render(self, P, with_filter):
+        self.p.render(P, with_filter)
+
 
 class ShardedProjector:
     """Runs the frame sequence over `group`; every rank ends with the full frame.
@@ -80,6 +83,9 @@ class ShardedProjector:
 
     def render(self, P, with_filter=False):
         lo = self.local
+        if self.world == 1 and hasattr(lo, "render"):
+            lo.render(P, with_filter)  # no exchange step: the fused whole-frame call
+            return
         lo.clear()
         lo.min_depth_pass(P)
         if self.world > 1:

@@ -149,3 +149,45 @@ def test_errors(pkg, projector):
     with pytest.raises(pkg.RtrError) as e:
         projector.project(P, want_img=False, want_depth=False)
     assert e.value.code == pkg._lib.RTR_ERR_NO_OUTPUT
+
+
+def test_two_shards_with_external_min_sum(pkg, orc):
+    """The multi-GPU frame sequence on ONE GPU: two contexts own the two halves of the cloud,
+    the exchange steps are done on zero-copy torch views of their device buffers (the same
+    views bench.py hands to RCCL).  Result must equal the single-context frame."""
+    import torch
+    n, W, H = 120_000, 640, 480
+    xyzw, rgba = orc.generate("room_shell", 21, 0, n, n)
+    P = pkg.orbit_projection(300, W, H)
+    ref = orc.project(xyzw, rgba, P, W, H)
+    reff = orc.filter(ref["depth_bits"], ref["img"])
+    for mode in (2, 0):
+        locs = []
+        for r in range(2):
+            lo, hi = pkg.shard_range(n, r, 2)
+            p = pkg.Projector(0)
+            p.set_option("mode", mode)
+            p.upload_points(xyzw[lo:hi], rgba[lo:hi])
+            p.set_resolution(W, H)
+            loc = pkg.sharded.HipLocal(p)
+            loc.bind_stream()
+            locs.append(loc)
+        for loc in locs:
+            loc.clear()
+            loc.min_depth_pass(P)
+        d = torch.minimum(locs[0].depth_tensor(), locs[1].depth_tensor())
+        for loc in locs:
+            loc.depth_tensor().copy_(d)
+            loc.accumulate_pass(P)
+        a = locs[0].accum_tensor() + locs[1].accum_tensor()
+        for loc in locs:
+            loc.accum_tensor().copy_(a)
+            loc.resolve()
+            loc.filter()
+        torch.cuda.synchronize()
+        for loc in locs:
+            assert np.array_equal(loc.p.download(pkg._lib.BUF_ACCUM), ref["acc"])
+            assert np.array_equal(loc.p.download(pkg._lib.BUF_IMAGE), reff["img"])
+            assert np.array_equal(loc.p.download(pkg._lib.BUF_DEPTH), reff["depth"].view(np.uint32))
+            assert np.array_equal(loc.p.download(pkg._lib.BUF_TENSOR).reshape(5, H, W), reff["tensor"])
+            loc.p.close()

@@ -1,0 +1,106 @@
+"""CPU: host-side logic and the C-ABI surface (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import HAS_GPU, ROOT
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(ROOT, "include", "rtr.h")).read()
+    declared = sorted(set(re.findall(r"\b(rtr_[a-z_]+)\s*\(", hdr)))
+    assert declared, "no declarations found"
+    lib = pkg._lib.lib()
+    for name in declared:
+        assert hasattr(lib, name), "librtr_hip.so does not export %s" % name
+    assert sorted(pkg.SYMBOLS) == declared
+    assert lib.rtr_abi_version() == 1
+
+
+def test_default_params(pkg):
+    p = pkg.RtrParams()
+    pkg._lib.lib().rtr_default_params(C.byref(p))
+    # render.cu:106, project_cloud.cu:23-25
+    assert (p.depth_window, p.filter_strength, p.gradient_threshold, p.levels) == (
+        np.float32(0.02), np.float32(1.025), np.float32(0.03), 4)
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU failure mode")
+def test_create_fails_loudly_without_gpu(pkg):
+    with pytest.raises(pkg.RtrError) as e:
+        pkg.Projector(0)
+    assert e.value.code == pkg._lib.RTR_ERR_HIP and "no CPU fallback" in str(e.value)
+
+
+def test_compose_projection_three_ways(pkg, orc):
+    """Python host mirror == oracle C == C ABI (pure host function), bit for bit."""
+    rng = np.random.default_rng(5)
+    lib = pkg._lib.lib()
+    for trial in range(200):
+        K = np.array([[rng.uniform(100, 4000), rng.uniform(-2, 2) if trial % 3 == 0 else 0.0, rng.uniform(0, 4000)],
+                      [0, rng.uniform(100, 4000), rng.uniform(0, 3000)], [0, 0, 1.0]])
+        E = pkg.orbit_pose(trial * 7)
+        E[:3, 3] += rng.normal(size=3)
+        a = pkg.compose_projection(K, E)
+        b = orc.compose_projection(K, E)
+        c = np.empty(16, np.float32)
+        Kc, Ec = np.ascontiguousarray(K.reshape(9)), np.ascontiguousarray(E.reshape(16))
+        assert lib.rtr_compose_projection(Kc.ctypes.data_as(C.c_void_p), Ec.ctypes.data_as(C.c_void_p),
+                                          c.ctypes.data_as(C.c_void_p)) == 0
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+
+
+def test_compose_projection_structure(pkg):
+    # project_cloud.cu:318: rows 2-3 of P are rows 2-3 of E (cast to float); rows 0-1 are
+    # fx*E0 + cx*E2 and fy*E1 + cy*E2 -- each a sum of two fp32 products (zero skew)
+    cal = pkg.benchmark_calibration(1920, 1080)
+    E = pkg.orbit_pose(123)
+    P = pkg.compose_projection(cal.getIntrinsicsMatrix(), E).reshape(4, 4)
+    Ef = E.astype(np.float32)
+    assert np.array_equal(P[2], Ef[2]) and np.array_equal(P[3], Ef[3])
+    fx, cx = np.float32(1536.0), np.float32(960.0)
+    assert np.array_equal(P[0], (fx * Ef[0]).astype(np.float32) + (cx * Ef[2]).astype(np.float32))
+
+
+def test_orbit_pose_is_rigid(pkg):
+    for k in (0, 1, 250, 999, 1000):
+        E = pkg.orbit_pose(k)
+        R, t = E[:3, :3], E[:3, 3]
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and np.isclose(np.linalg.det(R), 1.0)
+        c = -R.T @ t  # camera centre: on the r = 1.5 circle at y = 0
+        assert np.isclose(np.hypot(c[0], c[2]), 1.5) and abs(c[1]) < 1e-12
+    assert np.allclose(pkg.orbit_pose(0), pkg.orbit_pose(1000))
+
+
+def test_calibration_mirror(pkg):
+    cal = pkg.CameraCalibration()
+    assert (cal.getWidth(), cal.getHeight()) == (640, 480)  # CameraCalibration.cpp:5-10
+    cal = pkg.benchmark_calibration(3840, 2160)
+    K = cal.getIntrinsicsMatrix()
+    assert (K[0, 0], K[1, 1], K[0, 2], K[1, 2]) == (3072.0, 3072.0, 1920.0, 1080.0)
+
+
+def test_generator_is_counter_based(orc):
+    """Any shard equals the same slice of the whole (what lets every GPU synthesise its shard)."""
+    for scene in ("uniform_box", "room_shell"):
+        total = 50_000
+        full = orc.generate(scene, 0xC0FFEE05, 0, total, total)
+        for lo, hi in ((0, 1), (12_345, 23_456), (49_000, 50_000)):
+            part = orc.generate(scene, 0xC0FFEE05, lo, hi - lo, total)
+            assert np.array_equal(part[0].view(np.uint32), full[0][lo:hi].view(np.uint32))
+            assert np.array_equal(part[1], full[1][lo:hi])
+        xyz = full[0][:, :3]
+        assert xyz[:, 0].min() >= -4 and xyz[:, 0].max() <= 4 and abs(xyz[:, 1]).max() <= 1.5
+        assert (full[0][:, 3] == 1).all() and (full[1][:, 3] == 255).all()
+
+
+def test_room_shell_is_spatially_coherent(orc):
+    xyzw, _ = orc.generate("room_shell", 1, 0, 200_000, 200_000)
+    step = np.linalg.norm(np.diff(xyzw[:, :3], axis=0), axis=1)
+    assert np.median(step) < 0.1  # consecutive indices are spatial neighbours (Morton order)
+    box, _ = orc.generate("uniform_box", 1, 0, 200_000, 200_000)
+    assert np.median(np.linalg.norm(np.diff(box[:, :3], axis=0), axis=1)) > 1.0
