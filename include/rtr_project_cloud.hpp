@@ -1,0 +1,93 @@
+// rtr_project_cloud.hpp -- header-only C++ facade with the reference's ProjectCloud surface
+// (reference: src/RTRenderer/include/project_cloud.h:11-19) over the C ABI of rtr.h.
+//
+// The reference's header hard-wires cv::Mat, cv::Matx44d, CameraCalibration and
+// std::unordered_map<int, OctreeGrid::Block>.  None of OpenCV / glm is in this build image,
+// so the facade is written against the *members the reference actually uses* and accepts any
+// types that provide them -- the reference's own types satisfy every requirement, so
+// `rtr::ProjectCloud` is a source-level drop-in for `::ProjectCloud` in
+// example/render_trajectory/main.cpp:87-96 and cloudreader.cpp:233-246:
+//   Grid        : iterable of pairs whose .second has .positions (elements with .x .y .z) and
+//                 .colors (elements indexable [0..2])            (Octreegrid.h:16-21,162-180)
+//   Calibration : getWidth(), getHeight(), getIntrinsicsMatrix()(r,c)   (CameraCalibration.h)
+//   Extrinsics  : operator()(r,c) -> double, world->camera              (cv::Matx44d)
+//   Image       : template ptr<T>() -> T*  (cv::Mat::ptr<uint8_t>() / ptr<float>()),
+//                 caller-allocated CV_8UC3 / CV_32F of size W x H      (main.cpp:93-94)
+// Return codes as in project_cloud.cu:268-312: 1 on success, -1 when both outputs are null.
+// Unlike the reference (exit(1) on CUDA errors, project_cloud.cu:13-17) failures throw.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rtr.h"
+
+namespace rtr {
+
+class ProjectCloud {
+public:
+    template <class Grid>
+    explicit ProjectCloud(const Grid& grid, const std::string& modelFilename = std::string(""), int device = 0)
+        : model_filename_(modelFilename) {
+        // OctreeGrid::getVertexPositions / getVertexColors (Octreegrid.h:162-180)
+        std::vector<float> xyzw;
+        std::vector<uint8_t> rgba;
+        for (const auto& pair : grid) {
+            for (const auto& p : pair.second.positions) {
+                xyzw.push_back(p.x); xyzw.push_back(p.y); xyzw.push_back(p.z); xyzw.push_back(1.0f);
+            }
+            for (const auto& c : pair.second.colors) {
+                rgba.push_back(c[0]); rgba.push_back(c[1]); rgba.push_back(c[2]); rgba.push_back(255);
+            }
+        }
+        check(nullptr, rtr_create(&ctx_, device));
+        check(ctx_, rtr_upload_points(ctx_, xyzw.data(), 16, rgba.data(), 4, xyzw.size() / 4));
+    }
+    ProjectCloud(const ProjectCloud&) = delete;  // owns device buffers (the reference forgets this)
+    ProjectCloud& operator=(const ProjectCloud&) = delete;
+    ~ProjectCloud() { rtr_destroy(ctx_); }
+
+    template <class Calibration, class Extrinsics, class Image>
+    int computeRGBD(const Calibration& calibration, const Extrinsics& extrinsics, Image* color, Image* depth) {
+        return frame(calibration, extrinsics, color, depth, false);
+    }
+    template <class Calibration, class Extrinsics, class Image>
+    int computeFilteredRGBD(const Calibration& calibration, const Extrinsics& extrinsics, Image* color, Image* depth) {
+        return frame(calibration, extrinsics, color, depth, true);
+    }
+    // computeFull (project_cloud.cu:437-493) = computeFilteredRGBD + the caller's U-Net on this
+    // device pointer: torch::from_blob(tensor(), {1,5,H,W}, fp16, kCUDA)   (project_cloud.cu:471)
+    void* tensor() const {
+        void* p = nullptr;
+        check(ctx_, rtr_device_buffer(ctx_, RTR_BUF_TENSOR, &p, nullptr));
+        return p;
+    }
+    rtr_ctx* context() const { return ctx_; }
+
+private:
+    template <class Calibration, class Extrinsics, class Image>
+    int frame(const Calibration& calibration, const Extrinsics& extrinsics, Image* color, Image* depth, bool filtered) {
+        if (color == nullptr && depth == nullptr) return -1;  // project_cloud.cu:270-273
+        double K[9], E[16];
+        const auto Km = calibration.getIntrinsicsMatrix();
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) K[3 * r + c] = Km(r, c);
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) E[4 * r + c] = extrinsics(r, c);
+        float P[16];
+        rtr_compose_projection(K, E, P);  // project_cloud.cu:318
+        check(ctx_, rtr_set_resolution(ctx_, calibration.getWidth(), calibration.getHeight()));  // :275-298
+        uint8_t* c8 = color ? color->template ptr<uint8_t>() : nullptr;
+        float* d32 = depth ? depth->template ptr<float>() : nullptr;
+        check(ctx_, filtered ? rtr_project_filtered(ctx_, P, c8, d32) : rtr_project(ctx_, P, c8, d32));
+        return 1;
+    }
+    static void check(const rtr_ctx* c, int rc) {
+        if (rc != RTR_OK) throw std::runtime_error(std::string("rtr: ") + rtr_last_error(c));
+    }
+    rtr_ctx* ctx_ = nullptr;
+    std::string model_filename_;
+};
+
+}  // namespace rtr
