@@ -64,10 +64,10 @@ void rtr_default_params(rtr_params *p);
 int rtr_set_params(rtr_ctx *ctx, const rtr_params *p);
 int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
 /* Tuning knobs that never change the frame.
- *  "mode": 2 (default) tile-binned -- the cloud is streamed ONCE, in-frustum points are
+ *  "mode": 1 (default) tile-binned -- the cloud is streamed ONCE, in-frustum points are
  *          counting-sorted by 32-row screen tile and a per-tile LDS z-buffer does min +
- *          accumulate + resolve (no global atomics); 1 = candidate lists + global atomics;
- *          0 = the reference's structure: two full passes with atomicMin / atomicAdd
+ *          accumulate + resolve (no global atomics on the frame buffers); 0 = the
+ *          reference's structure: two full passes with atomicMin / atomicAdd
  *          (render.cu:53-130).
  *  "keep_accum": 1 = the whole-frame calls also write RTR_BUF_ACCUM (default 0; the phase
  *          calls always do). */
@@ -142,7 +142,7 @@ typedef enum {
     RTR_K_CLEAR = 0, RTR_K_MIN_DEPTH = 1, RTR_K_ACCUMULATE = 2, RTR_K_RESOLVE = 3, RTR_K_FILTER = 4,
     RTR_K_PROBE = 5, RTR_K_TILE = 6, RTR_K_BIN = 7, RTR_K_COUNT = 8
 } rtr_kernel_id;
-/* mode 2: RTR_K_MIN_DEPTH = streaming projection + candidate lists (T1), RTR_K_BIN = scan +
+/* mode 1: RTR_K_MIN_DEPTH = streaming projection + candidate lists (T1), RTR_K_BIN = scan +
  * counting sort by tile (T2-T3), RTR_K_TILE = per-tile z-buffer (T4); RTR_K_CLEAR / ACCUMULATE / RESOLVE are then only used by the phase calls. */
 /* Read-only probe: same loads and projection arithmetic as the point passes, no frame-
  * buffer traffic -- measures the streaming ceiling of the access pattern. */

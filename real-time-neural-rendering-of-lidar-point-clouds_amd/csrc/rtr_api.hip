@@ -39,19 +39,17 @@ struct rtr_ctx {
     rtr::FilterLevels lv{};
     int lv_levels = 0;  // levels the pyramid was allocated for
 
-    // survivor lists of the compact (single-stream) frame form
-    uint4 *list = nullptr;
-    uint32_t *counts = nullptr;
-    uint64_t list_n = 0;        // point count the list buffers were sized for
-    bool list_valid = false;    // list matches list_P / current cloud / resolution
+    // tile-binned pipeline: wave-private candidate lists (T1) and their tile-sorted copy (T3)
+    rtr::Lists lists{};
+    rtr::Bins bins{};
+    uint64_t list_n = 0;        // point count the list / bin buffers were sized for
+    int tiles_n = 0;            // tile count the histogram buffers were sized for
+    bool list_valid = false;    // bins match list_P / current cloud / resolution / window
     float list_P[12] = {0};
-    // tile-binned pipeline
-    uint4 *binned = nullptr;
-    uint32_t *tile_hist = nullptr, *tile_start = nullptr, *cursor = nullptr;
-    int tiles_n = 0;
-    int opt_mode = 2;           // 0 = two-pass atomics (the reference's structure), 1 = compact
-                                // list + atomics, 2 = tile-binned LDS z-buffer (default)
+    int opt_mode = 1;           // 0 = two-pass global atomics (the reference's structure),
+                                // 1 = tile-binned LDS z-buffer (default)
     int opt_keep_accum = 0;     // whole-frame calls also materialise RTR_BUF_ACCUM
+    int opt_probe = 0;          // rtr_stream_probe variant (experiments)
 
     // timing
     bool timing = false;
@@ -101,48 +99,52 @@ void free_frame(rtr_ctx *c) {
     c->list_valid = false;
     dfree(c->depth); dfree(c->acc); dfree(c->img); dfree(c->mask); dfree(c->part_min); dfree(c->part_max); dfree(c->tensor);
     for (int i = 1; i <= 8; ++i) dfree(c->lv.lv[i]);
-    dfree(c->tile_hist); dfree(c->tile_start); dfree(c->cursor);
+    dfree(c->bins.tile_hist); dfree(c->bins.tile_start); dfree(c->bins.cursor);
     c->tiles_n = 0;
     c->lv.lv[0] = nullptr;
     c->W = c->H = 0;
     c->lv_levels = 0;
 }
 
+void free_lists(rtr_ctx *c) {
+    dfree(c->lists.tiled); dfree(c->lists.depth); dfree(c->lists.idx); dfree(c->lists.counts);
+    dfree(c->bins.entries);
+    c->list_n = 0; c->list_valid = false;
+}
+
 void free_cloud(rtr_ctx *c) {
     dfree(c->x); dfree(c->y); dfree(c->z); dfree(c->rgba);
-    dfree(c->list); dfree(c->counts); dfree(c->binned);
-    c->list_n = 0; c->list_valid = false;
+    free_lists(c);
     c->n = c->cap = 0;
 }
 
 int ensure_tiles(rtr_ctx *c) {
     int nt = rtr::tile_count(c->W, c->H);
-    if (c->tile_hist && c->tiles_n == nt) return RTR_OK;
-    dfree(c->tile_hist); dfree(c->tile_start); dfree(c->cursor);
-    HIP_TRY(c, hipMalloc((void **)&c->tile_hist, (size_t)nt * 4));
-    HIP_TRY(c, hipMalloc((void **)&c->tile_start, (size_t)(nt + 1) * 4));
-    HIP_TRY(c, hipMalloc((void **)&c->cursor, (size_t)nt * 4));
-    HIP_TRY(c, hipMemsetAsync(c->tile_hist, 0, (size_t)nt * 4, c->stream));
+    if (c->bins.tile_hist && c->tiles_n == nt) return RTR_OK;
+    dfree(c->bins.tile_hist); dfree(c->bins.tile_start); dfree(c->bins.cursor);
+    HIP_TRY(c, hipMalloc((void **)&c->bins.tile_hist, (size_t)nt * 4));
+    HIP_TRY(c, hipMalloc((void **)&c->bins.tile_start, (size_t)(nt + 1) * 4));
+    HIP_TRY(c, hipMalloc((void **)&c->bins.cursor, (size_t)nt * 4));
+    HIP_TRY(c, hipMemsetAsync(c->bins.tile_hist, 0, (size_t)nt * 4, c->stream));
     c->tiles_n = nt;
     return RTR_OK;
 }
 
-int ensure_binned(rtr_ctx *c) {
-    if (c->binned || c->n == 0) return RTR_OK;
+// Worst-case reservations: a wave region holds every point its wave can see, so list space
+// needs neither atomics nor overflow handling (2 x 12 B x N; sized for a 288 GB part).
+int ensure_lists(rtr_ctx *c) {
+    if (c->lists.tiled && c->list_n == c->n) return RTR_OK;
+    free_lists(c);
     uint64_t waves = rtr::list_num_waves(c->n), cap = rtr::list_region_cap(c->n);
-    HIP_TRY(c, hipMalloc((void **)&c->binned, waves * cap * sizeof(uint4)));
-    return RTR_OK;
-}
-
-int ensure_list(rtr_ctx *c) {
-    if (c->list && c->list_n == c->n) return RTR_OK;
-    dfree(c->list); dfree(c->counts); dfree(c->binned);
-    c->list_valid = false;
-    uint64_t waves = rtr::list_num_waves(c->n), cap = rtr::list_region_cap(c->n);
-    if (waves == 0) { c->list_n = c->n; return RTR_OK; }
-    HIP_TRY(c, hipMalloc((void **)&c->list, waves * cap * sizeof(uint4)));
-    HIP_TRY(c, hipMalloc((void **)&c->counts, waves * sizeof(uint32_t)));
+    c->lists.region_cap = cap;
     c->list_n = c->n;
+    if (waves == 0) return RTR_OK;
+    size_t bytes = waves * cap * sizeof(uint32_t);
+    HIP_TRY(c, hipMalloc((void **)&c->lists.tiled, bytes));
+    HIP_TRY(c, hipMalloc((void **)&c->lists.depth, bytes));
+    HIP_TRY(c, hipMalloc((void **)&c->lists.idx, bytes));
+    HIP_TRY(c, hipMalloc((void **)&c->lists.counts, waves * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->bins.entries, waves * cap * sizeof(rtr::Entry)));
     return RTR_OK;
 }
 
@@ -309,9 +311,25 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
     if (!c) return RTR_ERR_INVALID;
     NEED(c, key != nullptr, "key is NULL");
     if (!strcmp(key, "mode")) {
-        NEED(c, value >= 0 && value <= 2, "mode must be 0, 1 or 2");
+        NEED(c, value == 0 || value == 1, "mode must be 0 or 1");
         c->opt_mode = value;
         c->list_valid = false;
+        return RTR_OK;
+    }
+    if (!strcmp(key, "point_grid")) {
+        NEED(c, value >= 1 && value <= 65535, "point_grid out of range");
+        DevGuard g(c->device);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        free_lists(c);
+        rtr::set_point_grid(value);
+        return RTR_OK;
+    }
+    if (!strcmp(key, "debug_skip")) {  // timing experiments only: the frame becomes wrong
+        rtr::set_debug_skip(value);
+        return RTR_OK;
+    }
+    if (!strcmp(key, "probe_variant")) {
+        c->opt_probe = value;
         return RTR_OK;
     }
     if (!strcmp(key, "keep_accum")) {
@@ -326,7 +344,7 @@ int rtr_stream_probe(rtr_ctx *c, const float P[16]) {
     NEED(c, P != nullptr, "P is NULL");
     if (int rc = check_frame(c)) return rc;
     DevGuard g(c->device);
-    { Timed t(c, RTR_K_PROBE); rtr::launch_stream_probe(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->minmax); }
+    { Timed t(c, RTR_K_PROBE); rtr::launch_stream_probe(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->minmax, c->opt_probe); }
     return launch_check(c, "stream_probe");
 }
 
@@ -488,17 +506,15 @@ int rtr_clear(rtr_ctx *c) {
 // T1..T3 of the tile-binned form: stream + candidate lists + tile histogram, scan, scatter
 static int bin_points(rtr_ctx *c, const float P[16]) {
     c->list_valid = false;
-    if (int rc = ensure_list(c)) return rc;
-    if (int rc = ensure_binned(c)) return rc;
+    if (int rc = ensure_lists(c)) return rc;
     if (int rc = ensure_tiles(c)) return rc;
     {
         Timed t(c, RTR_K_MIN_DEPTH);
-        rtr::launch_project_bin(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->list, c->counts, c->tile_hist);
+        rtr::launch_project_bin(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->lists, c->bins.tile_hist);
     }
     {
         Timed t(c, RTR_K_BIN);
-        rtr::launch_bin_sort(c->stream, cloud_of(c), c->W, c->H, c->list, c->counts, c->binned, c->tile_hist,
-                             c->tile_start, c->cursor);
+        rtr::launch_bin_sort(c->stream, cloud_of(c), c->W, c->H, c->lists, c->bins);
     }
     memcpy(c->list_P, P, sizeof c->list_P);
     c->list_valid = true;
@@ -511,25 +527,14 @@ int rtr_min_depth_pass(rtr_ctx *c, const float P[16]) {
     if (int rc = check_frame(c)) return rc;
     DevGuard g(c->device);
     c->list_valid = false;
-    if (c->opt_mode == 2) {
+    if (c->opt_mode == 1) {
         if (int rc = bin_points(c, P)) return rc;
         Timed t(c, RTR_K_TILE);
-        rtr::launch_tile(c->stream, 1, cloud_of(c), c->W, c->H, c->binned, c->tile_start, c->prm.depth_window, c->depth,
-                         c->acc, c->img, 0);
-        return launch_check(c, "min_depth_pass");
-    }
-    const bool compact = c->opt_mode == 1 && c->n > 0;
-    if (compact) {
-        if (int rc = ensure_list(c)) return rc;
-    }
-    {
+        rtr::launch_tile(c->stream, 1, cloud_of(c), c->W, c->H, c->bins, c->prm.depth_window, c->depth, c->acc, c->img,
+                         0);
+    } else {
         Timed t(c, RTR_K_MIN_DEPTH);
-        rtr::launch_min_depth(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->depth, c->prm.depth_window,
-                              compact ? c->list : nullptr, compact ? c->counts : nullptr);
-    }
-    if (compact) {
-        memcpy(c->list_P, P, sizeof c->list_P);
-        c->list_valid = true;
+        rtr::launch_min_depth(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->depth);
     }
     return launch_check(c, "min_depth_pass");
 }
@@ -539,18 +544,16 @@ int rtr_accumulate_pass(rtr_ctx *c, const float P[16]) {
     NEED(c, P != nullptr, "P is NULL");
     if (int rc = check_frame(c)) return rc;
     DevGuard g(c->device);
-    // lists / bins are only usable for the matrix (and window) they were built with;
-    // otherwise re-project the cloud like the reference does (render.cu:90-98)
-    const bool use_list = c->list_valid && memcmp(c->list_P, P, sizeof c->list_P) == 0;
-    if (use_list && c->opt_mode == 2) {
+    // the bins are only usable for the matrix they were built with; otherwise re-project
+    // the cloud like the reference does (render.cu:90-98)
+    const bool use_bins = c->opt_mode == 1 && c->list_valid && memcmp(c->list_P, P, sizeof c->list_P) == 0;
+    if (use_bins) {
         Timed t(c, RTR_K_TILE);
-        rtr::launch_tile(c->stream, 2, cloud_of(c), c->W, c->H, c->binned, c->tile_start, c->prm.depth_window, c->depth,
-                         c->acc, c->img, 1);
+        rtr::launch_tile(c->stream, 2, cloud_of(c), c->W, c->H, c->bins, c->prm.depth_window, c->depth, c->acc, c->img,
+                         1);
     } else {
         Timed t(c, RTR_K_ACCUMULATE);
-        const bool l = use_list && c->opt_mode == 1;
-        rtr::launch_accumulate(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->depth, c->acc, c->prm.depth_window,
-                               l ? c->list : nullptr, l ? c->counts : nullptr);
+        rtr::launch_accumulate(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->depth, c->acc, c->prm.depth_window);
     }
     return launch_check(c, "accumulate_pass");
 }
@@ -588,13 +591,13 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
         if (int rc = ensure_pyramid(c)) return rc;
     }
     int rc;
-    if (c->opt_mode == 2) {  // one launch does clear + min + accumulate + resolve per tile
+    if (c->opt_mode == 1) {  // one launch does clear + min + accumulate + resolve per tile
         DevGuard g(c->device);
         if ((rc = bin_points(c, P))) return rc;
         {
             Timed t(c, RTR_K_TILE);
-            rtr::launch_tile(c->stream, 0, cloud_of(c), c->W, c->H, c->binned, c->tile_start, c->prm.depth_window,
-                             c->depth, c->acc, c->img, c->opt_keep_accum);
+            rtr::launch_tile(c->stream, 0, cloud_of(c), c->W, c->H, c->bins, c->prm.depth_window, c->depth, c->acc,
+                             c->img, c->opt_keep_accum);
         }
         if ((rc = launch_check(c, "tile frame"))) return rc;
     } else {

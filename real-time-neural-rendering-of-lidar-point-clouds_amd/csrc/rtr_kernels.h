@@ -25,26 +25,38 @@ struct FilterLevels {
     int levels;
 };
 
+// wave-private candidate lists (SoA) written by T1 and the tile-sorted copy made by T3
+struct Lists {
+    uint32_t *tiled, *depth, *idx;  // [num_waves * region_cap] each
+    uint32_t *counts;               // [num_waves]
+    uint64_t region_cap;
+};
+struct Entry {  // 12 bytes, moved with one dwordx3 store
+    uint32_t tiled, depth, idx;
+};
+struct Bins {
+    Entry *entries;                             // entries counting-sorted by tile
+    uint32_t *tile_hist, *tile_start, *cursor;  // [ntiles], [ntiles + 1], [ntiles]
+};
+
 void launch_clear(hipStream_t s, uint32_t *depth, uint32_t *acc, size_t npix);
-// list / counts non-NULL selects the compact (single-stream) form: the min-depth pass
-// appends in-frustum candidates to per-wave lists which the accumulate pass consumes.
+// mode 0: the reference's structure (two full streams, global atomics)
+void launch_min_depth(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *depth);
+void launch_accumulate(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const uint32_t *depth,
+                       uint32_t *acc, float window);
+// mode 1 (default): tile-binned pipeline -- T1 stream + lists + histogram, T2 scan + T3 scatter,
+// T4 per-tile LDS z-buffer (tile mode 0 whole frame, 1 min only, 2 accumulate only)
+void set_debug_skip(int bits);         // timing experiments: bit0/1 T3 count/move, bit2/3/4 T4 min/acc/write-out
+void set_point_grid(int blocks);       // grid of the point kernels (tuning; invalidates list sizes)
 uint64_t list_region_cap(uint64_t n);  // entries per wave region
 uint64_t list_num_waves(uint64_t n);   // number of wave regions
-void launch_min_depth(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *depth, float window,
-                      uint4 *list, uint32_t *counts);
-void launch_accumulate(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const uint32_t *depth,
-                       uint32_t *acc, float window, const uint4 *list, const uint32_t *counts);
-// tile-binned pipeline (default): T1 stream + list + histogram, T2 scan, T3 scatter ...
 int tile_count(int W, int H);
-void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint4 *list, uint32_t *counts,
+void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const Lists &L,
                         uint32_t *tile_hist);
-void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const uint4 *list, const uint32_t *counts,
-                     uint4 *binned, uint32_t *tile_hist, uint32_t *tile_start, uint32_t *cursor);
-// ... T4 per-tile LDS z-buffer: mode 0 whole frame, 1 min only, 2 accumulate only
-void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const uint4 *binned,
-                 const uint32_t *tile_start, float window, uint32_t *depth, uint32_t *acc, uint8_t *img,
-                 int write_acc);
-void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *sink);
+void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const Lists &L, const Bins &B);
+void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const Bins &B, float window, uint32_t *depth,
+                 uint32_t *acc, uint8_t *img, int write_acc);
+void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *sink, int variant);
 void launch_resolve(hipStream_t s, const uint32_t *acc, uint8_t *img, size_t npix);
 void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, uint8_t *img, uint8_t *mask,
                    uint16_t *tensor, uint32_t *minmax, uint32_t *part_min, uint32_t *part_max, int W, int H,

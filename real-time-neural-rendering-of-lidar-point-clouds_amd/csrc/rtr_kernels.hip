@@ -13,7 +13,9 @@ namespace rtr {
 
 #define RTR_EMPTY 0x7F7FFFFFu
 constexpr int kBlock = 256;   // 4 waves
-constexpr int kPtGrid = 2048; // 256 CUs x 8 resident blocks, grid-stride the rest
+static int g_pt_grid = 1024;  // workgroups of the grid-stride point kernels (4 per CU measured best:
+                              // 1024 -> 205 us, 1536 -> 218, 2048 -> 239 for k_project_bin; 2048 does
+                              // not even fit: its 84 SGPRs admit 7 x 256 threads per CU, not 8)
 
 // one rounding per operation: plain operators under -ffp-contract=off (hipcc's __fmul_rn &
 // co. are the same plain operators; __fsqrt_rn is NOT correctly rounded, sqrtf is)
@@ -55,14 +57,14 @@ __global__ __launch_bounds__(kBlock) void k_clear(uint4 *__restrict__ depth4, ui
 void launch_clear(hipStream_t s, uint32_t *depth, uint32_t *acc, size_t npix) {
     size_t n_acc4 = npix, n_depth4 = npix / 4;
     int grid = (int)((n_acc4 + kBlock - 1) / kBlock);
-    if (grid > kPtGrid) grid = kPtGrid;
+    if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(k_clear, dim3(grid), dim3(kBlock), 0, s, (uint4 *)depth, (uint4 *)acc, n_depth4, n_acc4, depth,
                        npix);
 }
 
 // ---------------------------------------------------------------------------------
-// Point passes.  Both stream the SoA cloud with 16-byte non-temporal loads (1 KiB per
-// wave-instruction per coordinate; `nt` keeps the 1.2 GB stream from evicting the
+// Point passes.  All of them stream the SoA cloud with 16-byte non-temporal loads (1 KiB
+// per wave-instruction per coordinate; `nt` keeps the 1.2 GB stream from evicting the
 // frame buffers out of L2 / Infinity Cache) and project four points per lane.
 struct Quad {
     int pix[4];
@@ -70,14 +72,9 @@ struct Quad {
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
-typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld_stream(const float4 *p) {
     v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
     return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ uint4 ld_stream(const uint4 *p) {
-    v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 __device__ __forceinline__ Quad project_quad(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
@@ -96,31 +93,52 @@ __device__ __forceinline__ uint32_t ld_fresh(const uint32_t *p) {  // sc1: bypas
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// LDS histogram update with wave-level aggregation.  Same-address LDS atomics serialise
+// (measured: 6.7 M single-lane ds_add on mostly equal keys cost 20 us chip-wide), and in a
+// spatially coherent cloud nearly every lane of a wave carries the same tile.  The lanes
+// that share the first valid lane's key are handled by ONE atomic of their popcount; the
+// remaining lanes (tile borders, incoherent clouds) fall back to one atomic each.
+// Returns the value the lane's own "atomicAdd(&hist[key], 1)" would have returned.
+__device__ __forceinline__ uint32_t lds_hist_add(uint32_t *hist, uint32_t key, bool valid) {
+    const unsigned long long vm = __ballot(valid);
+    if (vm == 0ull) return 0u;
+    const int lane = threadIdx.x & 63;
+    const int first = __ffsll((long long)vm) - 1;
+    const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
+    const bool grp = valid && key == lead;
+    const unsigned long long gm = __ballot(grp);
+    uint32_t base = 0u;
+    if (lane == first) base = atomicAdd(&hist[lead], (uint32_t)__popcll(gm));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+    uint32_t res = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(gm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)gm, 0u));
+    if (valid && !grp) res = atomicAdd(&hist[key], 1u);
+    return res;
+}
+
+static int point_grid(uint64_t n4) {
+    uint64_t blocks = (n4 + kBlock - 1) / kBlock;
+    return (int)(blocks < (uint64_t)g_pt_grid ? blocks : (uint64_t)g_pt_grid);
+}
+
+void set_point_grid(int blocks) { g_pt_grid = blocks < 1 ? 1 : blocks; }
+
+static int g_debug_skip = 0;  // timing experiments only (results become wrong): see tools/
+void set_debug_skip(int bits) { g_debug_skip = bits; }
+
+// ---- mode 0: the reference's structure (two full streams + global atomics) -------------
 // A4 minDepthPass (render.cu:53-83).  Semantics = "atomicMin of every surviving point";
-// the reference's __match_any_sync aggregation is only a contention trick.  Here:
-//  * early-z: the atomic is skipped unless the point is strictly closer than what an
-//    L1-bypassing load sees.  A stale value is >= the true minimum, so staleness can only
-//    cause a redundant atomic, never a wrong result.  The four loads of a lane are issued
-//    together (culled points read a dummy pixel) so their latencies overlap.
-//  * COMPACT: every in-frustum point that can still pass the accumulate pass's window
-//    test (render.cu:106) is appended as (pixel, depth bits, point index) to a list
-//    private to the wave, so the accumulate pass never re-reads the cloud.  Dropping
-//    d > cur + window is safe: cur >= final minimum and fp32 add is monotone, hence
-//    d > final + window as well.  Wave-private regions need no atomics and no LDS: the
-//    write position is a wave-uniform counter advanced by ballot popcounts.
-template <bool COMPACT>
+// the reference's __match_any_sync aggregation is only a contention trick.  Early-z: the
+// atomic is skipped unless the point is strictly closer than what an L1-bypassing load
+// sees.  A stale value is >= the true minimum, so staleness can only cause a redundant
+// atomic, never a wrong result.  The four loads of a lane are issued together (culled
+// points read a dummy pixel) so their latencies overlap.
 __global__ __launch_bounds__(kBlock) void k_min_depth(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
                                                       const float4 *__restrict__ z4, uint64_t n4, Proj P, int W, int H,
-                                                      uint32_t *__restrict__ depth, float window,
-                                                      uint4 *__restrict__ list, uint32_t *__restrict__ counts,
-                                                      uint64_t region_cap) {
+                                                      uint32_t *__restrict__ depth) {
     const float fW = (float)W, fH = (float)H;
-    const uint64_t gtid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const int lane = threadIdx.x & 63;
-    uint4 *my = COMPACT ? list + (gtid >> 6) * region_cap : nullptr;
-    uint32_t fill = 0;
-    for (uint64_t i = gtid; i < n4; i += stride) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
         Quad q = project_quad(x4, y4, z4, i, P, W, H, fW, fH);
         bool any = (q.pix[0] & q.pix[1] & q.pix[2] & q.pix[3]) >= 0;  // some sign bit clear
         if (__ballot(any) == 0ull) continue;                          // wave-uniform skip
@@ -130,67 +148,30 @@ __global__ __launch_bounds__(kBlock) void k_min_depth(const float4 *__restrict__
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             uint32_t b = __float_as_uint(q.d[k]);
-            bool in = q.pix[k] >= 0;
-            if (in && b < cur[k]) atomicMin(&depth[q.pix[k]], b);
-            if (COMPACT) {
-                bool keep = in && !(q.d[k] > f_add(__uint_as_float(cur[k]), window));
-                unsigned long long m = __ballot(keep);
-                if (keep) {
-                    uint32_t pos = fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    my[pos] = make_uint4((uint32_t)q.pix[k], b, (uint32_t)(4 * i + k), 0u);
-                }
-                fill += (uint32_t)__popcll(m);
-            }
+            if (q.pix[k] >= 0 && b < cur[k]) atomicMin(&depth[q.pix[k]], b);
         }
     }
-    if (COMPACT && lane == 0) counts[gtid >> 6] = fill;
 }
 
-static int point_grid(uint64_t n4) {
-    uint64_t blocks = (n4 + kBlock - 1) / kBlock;
-    return (int)(blocks < (uint64_t)kPtGrid ? blocks : (uint64_t)kPtGrid);
-}
-
-uint64_t list_region_cap(uint64_t n) {  // entries one wave can produce: its iterations x 64 lanes x 4 points
-    uint64_t n4 = (n + 3) / 4;
-    if (n4 == 0) return 0;
-    uint64_t threads = (uint64_t)point_grid(n4) * kBlock;
-    return ((n4 + threads - 1) / threads) * 256;
-}
-
-uint64_t list_num_waves(uint64_t n) {
-    uint64_t n4 = (n + 3) / 4;
-    return n4 ? (uint64_t)point_grid(n4) * (kBlock / 64) : 0;
-}
-
-void launch_min_depth(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *depth, float window,
-                      uint4 *list, uint32_t *counts) {
+void launch_min_depth(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *depth) {
     uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) return;
-    int grid = point_grid(n4);
-    if (list)
-        hipLaunchKernelGGL(k_min_depth<true>, dim3(grid), dim3(kBlock), 0, s, (const float4 *)c.x, (const float4 *)c.y,
-                           (const float4 *)c.z, n4, P, W, H, depth, window, list, counts, list_region_cap(c.n));
-    else
-        hipLaunchKernelGGL(k_min_depth<false>, dim3(grid), dim3(kBlock), 0, s, (const float4 *)c.x,
-                           (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, depth, window, nullptr, nullptr, 0);
+    hipLaunchKernelGGL(k_min_depth, dim3(point_grid(n4)), dim3(kBlock), 0, s, (const float4 *)c.x, (const float4 *)c.y,
+                       (const float4 *)c.z, n4, P, W, H, depth);
 }
 
-// ---------------------------------------------------------------------------------
-// A5 accumulatePass (render.cu:85-130): depth-window test against the (global) minimum,
-// integer colour sums.  The four u32 accumulators of a pixel (sum c0, sum c1, sum c2,
-// count; project_cloud.h:33) are updated with TWO 64-bit atomic adds on the same memory
-// layout: (c0 | c1 << 32) and (c2 | count << 32).  Identical to four u32 adds unless a
-// single channel sum passes 2^32, where the reference itself wraps (> 16.8 M points in
-// one pixel's window).
+// A5 accumulatePass (render.cu:85-130): re-project, depth-window test against the (global)
+// minimum, integer colour sums.  The four u32 accumulators of a pixel (sum c0, sum c1,
+// sum c2, count; project_cloud.h:33) are updated with TWO 64-bit atomic adds on the same
+// memory layout: (c0 | c1 << 32) and (c2 | count << 32).  Identical to four u32 adds unless
+// a single channel sum passes 2^32, where the reference itself wraps (> 16.8 M points in one
+// pixel's window).
 __device__ __forceinline__ void acc_add(uint32_t *__restrict__ acc, int pix, uint32_t c) {
     unsigned long long *a = reinterpret_cast<unsigned long long *>(acc) + 2 * (size_t)pix;
     atomicAdd(a + 0, (unsigned long long)(c & 0xFFu) | ((unsigned long long)((c >> 8) & 0xFFu) << 32));
     atomicAdd(a + 1, (unsigned long long)((c >> 16) & 0xFFu) | (1ull << 32));
 }
 
-// two-pass form: re-project the whole cloud (what the reference does)
 __global__ __launch_bounds__(kBlock) void k_accumulate(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
                                                        const float4 *__restrict__ z4,
                                                        const uint32_t *__restrict__ rgba, uint64_t n4, Proj P, int W,
@@ -214,77 +195,109 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const float4 *__restrict_
     }
 }
 
-// compact form: consume the per-wave survivor lists written by k_min_depth<true>
-__global__ __launch_bounds__(kBlock) void k_accumulate_list(const uint4 *__restrict__ list,
-                                                            const uint32_t *__restrict__ counts, uint64_t region_cap,
-                                                            const uint32_t *__restrict__ rgba,
-                                                            const uint32_t *__restrict__ depth,
-                                                            uint32_t *__restrict__ acc, float window) {
-    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    const uint4 *my = list + wave * region_cap;
-    const uint32_t cnt = counts[wave];
-    for (uint32_t e = lane; e < cnt; e += 64) {
-        uint4 r = ld_stream(my + e);
-        float m = __uint_as_float(depth[r.x]);
-        if (!(__uint_as_float(r.y) > f_add(m, window))) acc_add(acc, (int)r.x, rgba[r.z]);
-    }
-}
-
 void launch_accumulate(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const uint32_t *depth,
-                       uint32_t *acc, float window, const uint4 *list, const uint32_t *counts) {
+                       uint32_t *acc, float window) {
     uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) return;
-    int grid = point_grid(n4);
-    if (list)
-        hipLaunchKernelGGL(k_accumulate_list, dim3(grid), dim3(kBlock), 0, s, list, counts, list_region_cap(c.n),
-                           c.rgba, depth, acc, window);
-    else
-        hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(kBlock), 0, s, (const float4 *)c.x, (const float4 *)c.y,
-                           (const float4 *)c.z, c.rgba, n4, P, W, H, depth, acc, window);
+    hipLaunchKernelGGL(k_accumulate, dim3(point_grid(n4)), dim3(kBlock), 0, s, (const float4 *)c.x, (const float4 *)c.y,
+                       (const float4 *)c.z, c.rgba, n4, P, W, H, depth, acc, window);
 }
 
 // read-only probe: the same loads and projection arithmetic as the point passes but no
 // frame-buffer traffic -- the streaming ceiling of this access pattern.
+// Variants (experiments): 0 as the passes, 1 approximate reciprocal (VALU sensitivity),
+// 2 two quads in flight per lane, 3 plain (temporal) loads, 4 loads only (no projection).
+template <int V>
 __global__ __launch_bounds__(kBlock) void k_stream_probe(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
                                                          const float4 *__restrict__ z4, uint64_t n4, Proj P, int W,
                                                          int H, uint32_t *__restrict__ sink) {
     const float fW = (float)W, fH = (float)H;
     uint64_t stride = (uint64_t)gridDim.x * kBlock;
     uint32_t h = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
-        Quad q = project_quad(x4, y4, z4, i, P, W, H, fW, fH);
-        h += (uint32_t)(q.pix[0] ^ q.pix[1] ^ q.pix[2] ^ q.pix[3]);
+    if (V == 2) {
+        uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+        for (; i + stride < n4; i += 2 * stride) {
+            float4 X0 = ld_stream(x4 + i), Y0 = ld_stream(y4 + i), Z0 = ld_stream(z4 + i);
+            float4 X1 = ld_stream(x4 + i + stride), Y1 = ld_stream(y4 + i + stride), Z1 = ld_stream(z4 + i + stride);
+            float d;
+            h += project_point(P, X0.x, Y0.x, Z0.x, W, H, fW, fH, d) ^ project_point(P, X0.y, Y0.y, Z0.y, W, H, fW, fH, d) ^
+                 project_point(P, X0.z, Y0.z, Z0.z, W, H, fW, fH, d) ^ project_point(P, X0.w, Y0.w, Z0.w, W, H, fW, fH, d);
+            h += project_point(P, X1.x, Y1.x, Z1.x, W, H, fW, fH, d) ^ project_point(P, X1.y, Y1.y, Z1.y, W, H, fW, fH, d) ^
+                 project_point(P, X1.z, Y1.z, Z1.z, W, H, fW, fH, d) ^ project_point(P, X1.w, Y1.w, Z1.w, W, H, fW, fH, d);
+        }
+        if (i < n4) {
+            Quad q = project_quad(x4, y4, z4, i, P, W, H, fW, fH);
+            h += (uint32_t)(q.pix[0] ^ q.pix[1] ^ q.pix[2] ^ q.pix[3]);
+        }
+    } else {
+        for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+            if (V == 0) {
+                Quad q = project_quad(x4, y4, z4, i, P, W, H, fW, fH);
+                h += (uint32_t)(q.pix[0] ^ q.pix[1] ^ q.pix[2] ^ q.pix[3]);
+            } else if (V == 3) {
+                float4 X = x4[i], Y = y4[i], Z = z4[i];
+                float d;
+                h += project_point(P, X.x, Y.x, Z.x, W, H, fW, fH, d) ^ project_point(P, X.y, Y.y, Z.y, W, H, fW, fH, d) ^
+                     project_point(P, X.z, Y.z, Z.z, W, H, fW, fH, d) ^ project_point(P, X.w, Y.w, Z.w, W, H, fW, fH, d);
+            } else if (V == 4) {
+                float4 X = ld_stream(x4 + i), Y = ld_stream(y4 + i), Z = ld_stream(z4 + i);
+                h += __float_as_uint(X.x) ^ __float_as_uint(Y.y) ^ __float_as_uint(Z.z) ^ __float_as_uint(X.w) ^
+                     __float_as_uint(Y.x) ^ __float_as_uint(Z.y);
+            } else {  // V == 1: v_rcp_f32 instead of the IEEE divide (NOT contract-conforming)
+                float4 X = ld_stream(x4 + i), Y = ld_stream(y4 + i), Z = ld_stream(z4 + i);
+                const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float rx = f_add(fmaf(P.m[2], zs[k], fmaf(P.m[1], ys[k], f_mul(P.m[0], xs[k]))), P.m[3]);
+                    float ry = f_add(fmaf(P.m[6], zs[k], fmaf(P.m[5], ys[k], f_mul(P.m[4], xs[k]))), P.m[7]);
+                    float rz = f_add(fmaf(P.m[10], zs[k], fmaf(P.m[9], ys[k], f_mul(P.m[8], xs[k]))), P.m[11]);
+                    float inv = __builtin_amdgcn_rcpf(rz);
+                    float fu = rintf(f_mul(rx, inv)), fv = rintf(f_mul(ry, inv));
+                    bool ok = (rz > 0.0f) && (fu >= 0.0f) && (fu < fW) && (fv >= 0.0f) && (fv < fH);
+                    h += ok ? (uint32_t)((int)fv * W + (int)fu) : 0xFFFFFFFFu;
+                }
+            }
+        }
     }
     if (h == 0x12345678u) sink[0] = h;  // practically never; keeps the work alive
 }
 
-void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *sink) {
+void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *sink, int variant) {
     uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) return;
-    hipLaunchKernelGGL(k_stream_probe, dim3(point_grid(n4)), dim3(kBlock), 0, s, (const float4 *)c.x,
-                       (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, sink);
+    dim3 g(point_grid(n4)), b(kBlock);
+    const float4 *x = (const float4 *)c.x, *y = (const float4 *)c.y, *z = (const float4 *)c.z;
+    switch (variant) {
+        case 1: hipLaunchKernelGGL(k_stream_probe<1>, g, b, 0, s, x, y, z, n4, P, W, H, sink); break;
+        case 2: hipLaunchKernelGGL(k_stream_probe<2>, g, b, 0, s, x, y, z, n4, P, W, H, sink); break;
+        case 3: hipLaunchKernelGGL(k_stream_probe<3>, g, b, 0, s, x, y, z, n4, P, W, H, sink); break;
+        case 4: hipLaunchKernelGGL(k_stream_probe<4>, g, b, 0, s, x, y, z, n4, P, W, H, sink); break;
+        default: hipLaunchKernelGGL(k_stream_probe<0>, g, b, 0, s, x, y, z, n4, P, W, H, sink); break;
+    }
 }
 
 // =================================================================================
-// Tile-binned pipeline (the default frame form).
+// mode 1 (default): tile-binned pipeline.
 //
 // Scattered device-scope atomics run at a few 10^10 per second on MI355X (they execute
-// at the memory side), which is what bounds the atomic forms above once the stream
-// itself runs at ~6 TB/s.  The binned form has NO global atomics on the frame buffers:
-//   T1 k_project_bin : stream the cloud once (12 B/pt), append every in-frustum point
-//                      as (pixel, depth bits, point index, tiled pixel index) to a list
+// at the memory side), which is what bounds the atomic form above once the stream itself
+// runs at ~6 TB/s.  The binned form has NO global atomics on the frame buffers:
+//   T1 k_project_bin : stream the cloud once (12 B/pt), append every in-frustum point as
+//                      (tile-major pixel index, depth bits, point index) to SoA lists
 //                      private to the wave, count points per 32-row screen tile in LDS;
 //   T2 k_tile_scan   : exclusive scan of the tile histogram (one workgroup);
 //   T3 k_scatter     : counting-sort the entries by tile (LDS ranks, one contiguous
 //                      atomic claim per workgroup and tile);
-//   T4 k_tile_*      : one workgroup per tile keeps the tile's depth and accumulators in
+//   T4 k_tile<>      : one workgroup per tile keeps the tile's depth and accumulators in
 //                      LDS: ds_min (render.cu:81), barrier, window test + ds_add
 //                      (render.cu:106,125-128), barrier, resolve (render.cu:147-162) and
 //                      writes every pixel of the tile -- clear, both reference passes and
 //                      the resolve of one tile in one launch.
-// Results are identical to the atomic forms because min and integer sums commute.
+// Results are identical to the atomic form because min and integer sums commute.
 constexpr int kTileH = 32;
+constexpr int kTileThreads = 512;
+constexpr int kTileBatch = 8;   // entries in flight per thread in k_tile
+constexpr int kScatterWPR = 2;  // k_scatter waves per list region
 
 struct TileGeom {
     int tw_shift;  // log2(tile width): 5 (32x32) or 6 (64x32)
@@ -306,60 +319,96 @@ __host__ __device__ inline TileGeom tile_geom(int W, int H) {
 
 int tile_count(int W, int H) { return tile_geom(W, H).ntiles; }
 
-// projection that also reports the tile-major pixel index
-__device__ __forceinline__ bool project_tiled(const Proj &P, float x, float y, float z, int W, float fW, float fH,
-                                              const TileGeom &g, uint32_t &pix, uint32_t &dbits, uint32_t &tiled) {
-    float rx = f_add(fmaf(P.m[2], z, fmaf(P.m[1], y, f_mul(P.m[0], x))), P.m[3]);
-    float ry = f_add(fmaf(P.m[6], z, fmaf(P.m[5], y, f_mul(P.m[4], x))), P.m[7]);
-    float rz = f_add(fmaf(P.m[10], z, fmaf(P.m[9], y, f_mul(P.m[8], x))), P.m[11]);
-    float inv = 1.0f / rz;
-    float fu = rintf(f_mul(rx, inv));
-    float fv = rintf(f_mul(ry, inv));
-    bool ok = (rz > 0.0f) && (fu >= 0.0f) && (fu < fW) && (fv >= 0.0f) && (fv < fH);
-    int u = (int)fu, v = (int)fv;
-    pix = (uint32_t)(v * W + u);
-    dbits = __float_as_uint(rz);
-    uint32_t tile = (uint32_t)((v >> 5) * g.tiles_x + (u >> g.tw_shift));
-    uint32_t local = (uint32_t)(((v & 31) << g.tw_shift) | (u & ((1 << g.tw_shift) - 1)));
-    tiled = (tile << (g.tw_shift + 5)) | local;
-    return ok;
+uint64_t list_region_cap(uint64_t n) {  // entries one wave can produce: its iterations x 64 lanes x 4 points
+    uint64_t n4 = (n + 3) / 4;
+    if (n4 == 0) return 0;
+    uint64_t threads = (uint64_t)point_grid(n4) * kBlock;
+    return ((n4 + threads - 1) / threads) * 256;
+}
+
+uint64_t list_num_waves(uint64_t n) {
+    uint64_t n4 = (n + 3) / 4;
+    return n4 ? (uint64_t)point_grid(n4) * (kBlock / 64) : 0;
 }
 
 // T1 ------------------------------------------------------------------------------
+// Wave-private list regions need no atomics and no overflow handling: the write position is
+// a wave-uniform counter advanced by ballot popcounts, a region holds every point its wave
+// can ever see.
+//
+// VALU matters here (a loads-only probe streams at 6.9 TB/s, with the projection arithmetic
+// at 6.0), so the quad is culled in three wave-uniform steps before the expensive part:
+//   1. r.z of the four points (render.cu:37,63); skip the quad if no lane has r.z > 0;
+//   2. r.x, r.y and a CONSERVATIVE frustum test (the exact test needs the quotient): a
+//      point is certainly outside when r.x < -0.75 r.z or r.x > (W + 0.25) r.z (same in y):
+//      the rounded quotient differs from r.x / r.z by < 2^-21 relative, i.e. < 0.01 px for
+//      W <= 8192, against margins of 0.25 px; only applied for r.z > 1e-30 so that no
+//      underflow enters the argument.  Skip the quad if no lane may be inside;
+//   3. the exact contract arithmetic (reciprocal, rintf, range test) for what is left.
+// Spatially coherent clouds (LiDAR block order) take the early exits for ~90 % of the waves.
 __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
                                                         const float4 *__restrict__ z4, uint64_t n4, Proj P, int W,
-                                                        int H, TileGeom g, uint4 *__restrict__ list,
-                                                        uint32_t *__restrict__ counts, uint64_t region_cap,
-                                                        uint32_t *__restrict__ tile_hist) {
+                                                        int H, TileGeom g, Lists L, uint32_t *__restrict__ tile_hist) {
     extern __shared__ uint32_t s_hist[];
     for (int t = threadIdx.x; t < g.ntiles; t += kBlock) s_hist[t] = 0;
     __syncthreads();
     const float fW = (float)W, fH = (float)H;
+    const float hiW = f_add(fW, 0.25f), hiH = f_add(fH, 0.25f);
     const uint64_t gtid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const int lane = threadIdx.x & 63;
-    const int tshift = g.tw_shift + 5;
-    uint4 *my = list + (gtid >> 6) * region_cap;
+    const int tshift = g.tw_shift + 5, twm = (1 << g.tw_shift) - 1;
+    const uint64_t base = (gtid >> 6) * L.region_cap;
+    uint32_t *__restrict__ my_t = L.tiled + base, *__restrict__ my_d = L.depth + base, *__restrict__ my_i = L.idx + base;
     uint32_t fill = 0;
     for (uint64_t i = gtid; i < n4; i += stride) {
         float4 X = ld_stream(x4 + i), Y = ld_stream(y4 + i), Z = ld_stream(z4 + i);
         const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+        float rz[4];
+        bool front = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            uint32_t pix, db, tiled;
-            bool in = project_tiled(P, xs[k], ys[k], zs[k], W, fW, fH, g, pix, db, tiled);
+            rz[k] = f_add(fmaf(P.m[10], zs[k], fmaf(P.m[9], ys[k], f_mul(P.m[8], xs[k]))), P.m[11]);
+            front = front || (rz[k] > 0.0f);  // render.cu:63 (NaN fails)
+        }
+        if (__ballot(front) == 0ull) continue;
+        float rx[4], ry[4];
+        bool maybe[4], any = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            rx[k] = f_add(fmaf(P.m[2], zs[k], fmaf(P.m[1], ys[k], f_mul(P.m[0], xs[k]))), P.m[3]);
+            ry[k] = f_add(fmaf(P.m[6], zs[k], fmaf(P.m[5], ys[k], f_mul(P.m[4], xs[k]))), P.m[7]);
+            const float z = rz[k], lo = f_mul(-0.75f, z);
+            const bool out = (z > 1e-30f) && ((rx[k] < lo) || (rx[k] > f_mul(hiW, z)) || (ry[k] < lo) || (ry[k] > f_mul(hiH, z)));
+            maybe[k] = (z > 0.0f) && !out;
+            any = any || maybe[k];
+        }
+        if (__ballot(any) == 0ull) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned long long mm = __ballot(maybe[k]);
+            if (mm == 0ull) continue;
+            float inv = 1.0f / rz[k];                 // correctly rounded (contract option B)
+            float fu = rintf(f_mul(rx[k], inv));      // render.cu:65
+            float fv = rintf(f_mul(ry[k], inv));      // render.cu:66
+            bool in = maybe[k] && (fu >= 0.0f) && (fu < fW) && (fv >= 0.0f) && (fv < fH);  // render.cu:68
             unsigned long long m = __ballot(in);
             if (m == 0ull) continue;
             if (in) {
+                int u = (int)fu, v = (int)fv;
+                uint32_t tile = (uint32_t)((v >> 5) * g.tiles_x + (u >> g.tw_shift));
+                uint32_t tiled = (tile << tshift) | (uint32_t)(((v & 31) << g.tw_shift) | (u & twm));
                 uint32_t pos = fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                my[pos] = make_uint4(pix, db, (uint32_t)(4 * i + k), tiled);
-                atomicAdd(&s_hist[tiled >> tshift], 1u);
+                my_t[pos] = tiled;
+                my_d[pos] = __float_as_uint(rz[k]);
+                my_i[pos] = (uint32_t)(4 * i + k);
+                lds_hist_add(s_hist, tile, true);  // exec = the in-frustum lanes
             }
             fill += (uint32_t)__popcll(m);
         }
     }
-    if (lane == 0) counts[gtid >> 6] = fill;
+    if (lane == 0) L.counts[gtid >> 6] = fill;
     __syncthreads();
     for (int t = threadIdx.x; t < g.ntiles; t += kBlock) {
         uint32_t c = s_hist[t];
@@ -397,30 +446,63 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *__restrict__ tile_
     if (threadIdx.x == 1023) tile_start[ntiles] = s_part[1023];
 }
 
-// T3: counting sort by tile.  Workgroup b re-reads the four wave lists that workgroup b
-// of T1 wrote (same grid), ranks entries per tile in LDS, claims a contiguous range per
-// tile with one returning atomic, then writes the entries to their tile's segment.
-__global__ __launch_bounds__(kBlock) void k_scatter(const uint4 *__restrict__ list, const uint32_t *__restrict__ counts,
-                                                    uint64_t region_cap, int ntiles, int tshift,
-                                                    uint32_t *__restrict__ cursor, uint4 *__restrict__ binned) {
-    extern __shared__ uint32_t s_cnt[];  // [ntiles] counts, then bases
-    for (int t = threadIdx.x; t < ntiles; t += kBlock) s_cnt[t] = 0;
+// T3: counting sort by tile.  Workgroup b re-reads the four wave lists that workgroup b of
+// T1 wrote (same grid): count per tile in LDS (reads only the 4-byte keys), claim a
+// contiguous range per tile with one returning atomic, then move the entries (one 12-byte
+// store each).  Four entries per lane are in flight at a time: the loops are latency-bound.
+template <int WPR>  // waves per list region: the loops are latency chains, more waves shorten them
+__global__ __launch_bounds__(kBlock * WPR) void k_scatter(Lists L, int ntiles, int tshift,
+                                                          uint32_t *__restrict__ cursor, Entry *__restrict__ binned,
+                                                          int dbg) {
+    constexpr int T = kBlock * WPR;
+    extern __shared__ uint32_t s_cnt[];  // [ntiles] counts, then running write positions
+    for (int t = threadIdx.x; t < ntiles; t += T) s_cnt[t] = 0;
     __syncthreads();
-    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    const uint4 *my = list + wave * region_cap;
-    const uint32_t cnt = counts[wave];
-    for (uint32_t e = lane; e < cnt; e += 64) atomicAdd(&s_cnt[my[e].w >> tshift], 1u);
-    __syncthreads();
-    for (int t = threadIdx.x; t < ntiles; t += kBlock) {
-        uint32_t c = s_cnt[t];
-        s_cnt[t] = c ? atomicAdd(&cursor[t], c) : 0u;  // now the base of this workgroup's run
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t region = (uint64_t)blockIdx.x * (kBlock / 64) + (w / WPR);
+    const uint32_t first = (uint32_t)(w % WPR) * 64 + lane, step = 64 * WPR;
+    const uint64_t base = region * L.region_cap;
+    const uint32_t *__restrict__ my_t = L.tiled + base, *__restrict__ my_d = L.depth + base,
+                                 *__restrict__ my_i = L.idx + base;
+    uint32_t cnt = L.counts[region];
+    if (dbg & 1) cnt = 0;
+    for (uint32_t e = first; e < cnt; e += 4 * step) {
+        uint32_t t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = (e + step * k < cnt) ? my_t[e + step * k] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lds_hist_add(s_cnt, t[k] >> tshift, t[k] != 0xFFFFFFFFu);
     }
     __syncthreads();
-    for (uint32_t e = lane; e < cnt; e += 64) {
-        uint4 r = my[e];
-        uint32_t pos = atomicAdd(&s_cnt[r.w >> tshift], 1u);
-        binned[pos] = r;
+    // claim this workgroup's run in every tile it touches; the returning atomics of four
+    // tiles are in flight together (their ~microsecond round trips would otherwise serialise)
+    for (int t0 = threadIdx.x; t0 < ntiles; t0 += 4 * T) {
+        uint32_t c[4], r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] = (t0 + k * T < ntiles) ? s_cnt[t0 + k * T] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = c[k] ? atomicAdd(&cursor[t0 + k * T], c[k]) : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (t0 + k * T < ntiles) s_cnt[t0 + k * T] = r[k];
+    }
+    __syncthreads();
+    if (dbg & 2) cnt = 0;
+    for (uint32_t e = first; e < cnt; e += 4 * step) {
+        uint32_t t[4], d[4], ix[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bool v = e + step * k < cnt;
+            t[k] = v ? my_t[e + step * k] : 0xFFFFFFFFu;
+            d[k] = v ? my_d[e + step * k] : 0u;
+            ix[k] = v ? my_i[e + step * k] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool v = t[k] != 0xFFFFFFFFu;
+            uint32_t pos = lds_hist_add(s_cnt, t[k] >> tshift, v);
+            if (v) binned[pos] = Entry{t[k], d[k], ix[k]};
+        }
     }
 }
 
@@ -428,22 +510,30 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const uint4 *__restrict__ li
 // depth / image / optionally the accumulators); MODE 1 = min only (depth = min(depth,
 // tile min): the phase call before the multi-GPU MIN all-reduce); MODE 2 = accumulate
 // only against the depth buffer in memory (acc += tile sums).
+// 512 threads and four entries in flight per thread: the heaviest tile (5-6 x the mean
+// entry count on the benchmark scenes) sets the launch time.
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_tile(const uint4 *__restrict__ binned,
-                                                 const uint32_t *__restrict__ tile_start,
-                                                 const uint32_t *__restrict__ rgba, TileGeom g, int W, int H,
-                                                 float window, uint32_t *__restrict__ depth,
-                                                 uint32_t *__restrict__ acc, uint8_t *__restrict__ img, int write_acc) {
+__global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__ binned,
+                                                        const uint32_t *__restrict__ tile_start,
+                                                        const uint32_t *__restrict__ rgba, TileGeom g, int W, int H,
+                                                        float window, uint32_t *__restrict__ depth,
+                                                        uint32_t *__restrict__ acc, uint8_t *__restrict__ img,
+                                                        int write_acc) {
     extern __shared__ uint32_t s_mem[];
     const int tpix = 32 << g.tw_shift;  // pixels per tile
     uint32_t *s_depth = s_mem;          // [tpix]
     uint32_t *s_acc = s_mem + tpix;     // [4 * tpix]
-    const int tile = blockIdx.x;
+    uint8_t *s_rgb = reinterpret_cast<uint8_t *>(s_mem + 5 * tpix);  // [3 * tpix] (MODE 0)
+    const int tile = blockIdx.x, tid = threadIdx.x;
     const int tx0 = (tile % g.tiles_x) << g.tw_shift, ty0 = (tile / g.tiles_x) * kTileH;
     const int tw = 1 << g.tw_shift, tmask = tpix - 1;
-    const uint32_t e0 = tile_start[tile], e1 = tile_start[tile + 1];
+    const uint32_t e0 = tile_start[tile];
+    uint32_t e1 = tile_start[tile + 1];
+    const int dbg = write_acc >> 8;
+    write_acc &= 0xFF;
+    constexpr uint32_t T = kTileThreads;
 
-    for (int p = threadIdx.x; p < tpix; p += kBlock) {
+    for (int p = tid; p < tpix; p += T) {
         if (MODE == 2) {
             int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
             s_depth[p] = (x < W && y < H) ? depth[(size_t)y * W + x] : RTR_EMPTY;
@@ -452,91 +542,134 @@ __global__ __launch_bounds__(kBlock) void k_tile(const uint4 *__restrict__ binne
         }
     }
     if (MODE != 1)
-        for (int p = threadIdx.x; p < 4 * tpix; p += kBlock) s_acc[p] = 0;
+        for (int p = tid; p < 4 * tpix; p += T) s_acc[p] = 0;
     __syncthreads();
-    if (MODE != 2) {
-        for (uint32_t e = e0 + threadIdx.x; e < e1; e += kBlock) {
-            uint4 r = binned[e];
-            atomicMin(&s_depth[r.w & tmask], r.y);  // render.cu:81
-        }
-        __syncthreads();
-    }
-    if (MODE != 1) {
-        for (uint32_t e = e0 + threadIdx.x; e < e1; e += kBlock) {
-            uint4 r = binned[e];
-            int p = r.w & tmask;
-            float m = __uint_as_float(s_depth[p]);
-            if (!(__uint_as_float(r.y) > f_add(m, window))) {  // render.cu:106
-                uint32_t c = rgba[r.z];
-                atomicAdd(&s_acc[4 * p + 0], c & 0xFFu);  // render.cu:125-128
-                atomicAdd(&s_acc[4 * p + 1], (c >> 8) & 0xFFu);
-                atomicAdd(&s_acc[4 * p + 2], (c >> 16) & 0xFFu);
-                atomicAdd(&s_acc[4 * p + 3], 1u);
+    if (MODE != 2 && !(dbg & 4)) {
+        for (uint32_t e = e0 + tid; e < e1; e += kTileBatch * T) {
+            uint32_t t[kTileBatch], d[kTileBatch];
+#pragma unroll
+            for (int k = 0; k < kTileBatch; ++k) {
+                uint32_t ee = e + k * T;
+                Entry r = (ee < e1) ? binned[ee] : Entry{0u, RTR_EMPTY, 0u};
+                t[k] = r.tiled;
+                d[k] = r.depth;
             }
+#pragma unroll
+            for (int k = 0; k < kTileBatch; ++k) atomicMin(&s_depth[t[k] & tmask], d[k]);  // render.cu:81
         }
         __syncthreads();
     }
-    // write-out: one thread per pixel, rows of the tile are contiguous in memory
-    for (int p = threadIdx.x; p < tpix; p += kBlock) {
+    if (MODE != 1 && !(dbg & 8)) {
+        for (uint32_t e = e0 + tid; e < e1; e += kTileBatch * T) {
+            uint32_t t[kTileBatch], d[kTileBatch], ix[kTileBatch];
+#pragma unroll
+            for (int k = 0; k < kTileBatch; ++k) {
+                uint32_t ee = e + k * T;
+                Entry r = (ee < e1) ? binned[ee] : Entry{0u, 0x7F800000u, 0u};  // +inf fails every window test
+                t[k] = r.tiled;
+                d[k] = r.depth;
+                ix[k] = r.idx;
+            }
+            bool hit[kTileBatch];
+            uint32_t c[kTileBatch];
+#pragma unroll
+            for (int k = 0; k < kTileBatch; ++k) {
+                float m = __uint_as_float(s_depth[t[k] & tmask]);
+                hit[k] = !(__uint_as_float(d[k]) > f_add(m, window));  // render.cu:106
+                c[k] = hit[k] ? rgba[ix[k]] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < kTileBatch; ++k)
+                if (hit[k]) {  // render.cu:125-128 as two 64-bit LDS adds: (c0 | c1 << 32), (c2 | count << 32)
+                    unsigned long long *a = reinterpret_cast<unsigned long long *>(s_acc) + 2 * (t[k] & tmask);
+                    atomicAdd(a + 0, (unsigned long long)(c[k] & 0xFFu) | ((unsigned long long)((c[k] >> 8) & 0xFFu) << 32));
+                    atomicAdd(a + 1, (unsigned long long)((c[k] >> 16) & 0xFFu) | (1ull << 32));
+                }
+        }
+        __syncthreads();
+    }
+    // write-out: rows of the tile are contiguous in memory
+    if (dbg & 16) return;
+    for (int p = tid; p < tpix; p += T) {
         int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
-        if (x >= W || y >= H) continue;
+        bool inb = x < W && y < H;
         size_t gp = (size_t)y * W + x;
         if (MODE == 0) {
-            depth[gp] = s_depth[p];
+            if (inb) depth[gp] = s_depth[p];
         } else if (MODE == 1) {
-            uint32_t old = depth[gp], v = s_depth[p];
-            if (v < old) depth[gp] = v;
+            if (inb) {
+                uint32_t old = depth[gp], v = s_depth[p];
+                if (v < old) depth[gp] = v;
+            }
         }
         if (MODE != 1) {
             uint32_t a0 = s_acc[4 * p], a1 = s_acc[4 * p + 1], a2 = s_acc[4 * p + 2], c = s_acc[4 * p + 3];
             if (MODE == 2) {
-                uint4 o = reinterpret_cast<uint4 *>(acc)[gp];
-                reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(o.x + a0, o.y + a1, o.z + a2, o.w + c);
+                if (inb) {
+                    uint4 o = reinterpret_cast<uint4 *>(acc)[gp];
+                    reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(o.x + a0, o.y + a1, o.z + a2, o.w + c);
+                }
             } else {
-                if (write_acc) reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(a0, a1, a2, c);
-                img[3 * gp + 0] = c ? (uint8_t)(a0 / c) : 0;  // render.cu:147-162
-                img[3 * gp + 1] = c ? (uint8_t)(a1 / c) : 0;
-                img[3 * gp + 2] = c ? (uint8_t)(a2 / c) : 0;
+                if (inb && write_acc) reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(a0, a1, a2, c);
+                s_rgb[3 * p + 0] = c ? (uint8_t)(a0 / c) : 0;  // render.cu:147-162
+                s_rgb[3 * p + 1] = c ? (uint8_t)(a1 / c) : 0;
+                s_rgb[3 * p + 2] = c ? (uint8_t)(a2 / c) : 0;
+            }
+        }
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        // image rows of the tile as dwords when the row segment is whole and 4-byte aligned
+        const int row_dw = (3 * tw) >> 2;  // 24 or 48 dwords per tile row
+        const bool fast = (tx0 + tw <= W) && ((W & 3) == 0);
+        if (fast) {
+            const uint32_t *s_rgb32 = reinterpret_cast<const uint32_t *>(s_rgb);
+            for (int q = tid; q < row_dw * kTileH; q += T) {
+                int r = q / row_dw, dw = q - r * row_dw, y = ty0 + r;
+                if (y < H) reinterpret_cast<uint32_t *>(img + ((size_t)y * W + tx0) * 3)[dw] = s_rgb32[r * row_dw + dw];
+            }
+        } else {
+            for (int q = tid; q < 3 * tpix; q += T) {
+                int p = q / 3, ch = q - 3 * p;
+                int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
+                if (x < W && y < H) img[((size_t)y * W + x) * 3 + ch] = s_rgb[q];
             }
         }
     }
 }
 
-void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint4 *list, uint32_t *counts,
+void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const Lists &L,
                         uint32_t *tile_hist) {
     TileGeom g = tile_geom(W, H);
     uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) return;
     hipLaunchKernelGGL(k_project_bin, dim3(point_grid(n4)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s,
-                       (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, g, list, counts,
-                       list_region_cap(c.n), tile_hist);
+                       (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, g, L, tile_hist);
 }
 
-void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const uint4 *list, const uint32_t *counts,
-                     uint4 *binned, uint32_t *tile_hist, uint32_t *tile_start, uint32_t *cursor) {
+void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const Lists &L, const Bins &B) {
     TileGeom g = tile_geom(W, H);
     uint64_t n4 = (c.n + 3) / 4;
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, tile_hist, tile_start, cursor, g.ntiles);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, B.tile_hist, B.tile_start, B.cursor, g.ntiles);
     if (n4 == 0) return;
-    hipLaunchKernelGGL(k_scatter, dim3(point_grid(n4)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s, list, counts,
-                       list_region_cap(c.n), g.ntiles, g.tw_shift + 5, cursor, binned);
+    hipLaunchKernelGGL(k_scatter<kScatterWPR>, dim3(point_grid(n4)), dim3(kBlock * kScatterWPR),
+                       g.ntiles * sizeof(uint32_t), s, L, g.ntiles, g.tw_shift + 5, B.cursor, B.entries, g_debug_skip & 3);
 }
 
-void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const uint4 *binned,
-                 const uint32_t *tile_start, float window, uint32_t *depth, uint32_t *acc, uint8_t *img,
-                 int write_acc) {
+void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const Bins &B, float window, uint32_t *depth,
+                 uint32_t *acc, uint8_t *img, int write_acc) {
     TileGeom g = tile_geom(W, H);
     size_t tpix = (size_t)32 << g.tw_shift;
-    size_t lds = (mode == 1 ? tpix : 5 * tpix) * sizeof(uint32_t);
+    size_t lds = (mode == 1 ? tpix : 5 * tpix) * sizeof(uint32_t) + (mode == 0 ? 3 * tpix : 0);
     if (mode == 0)
-        hipLaunchKernelGGL(k_tile<0>, dim3(g.ntiles), dim3(kBlock), lds, s, binned, tile_start, c.rgba, g, W, H, window,
-                           depth, acc, img, write_acc);
+        hipLaunchKernelGGL(k_tile<0>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start,
+                           c.rgba, g, W, H, window, depth, acc, img, write_acc | ((g_debug_skip >> 2) << 10));
     else if (mode == 1)
-        hipLaunchKernelGGL(k_tile<1>, dim3(g.ntiles), dim3(kBlock), lds, s, binned, tile_start, c.rgba, g, W, H, window,
-                           depth, acc, img, 0);
+        hipLaunchKernelGGL(k_tile<1>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start,
+                           c.rgba, g, W, H, window, depth, acc, img, 0);
     else
-        hipLaunchKernelGGL(k_tile<2>, dim3(g.ntiles), dim3(kBlock), lds, s, binned, tile_start, c.rgba, g, W, H, window,
-                           depth, acc, img, 1);
+        hipLaunchKernelGGL(k_tile<2>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start,
+                           c.rgba, g, W, H, window, depth, acc, img, 1);
 }
 
 // ---------------------------------------------------------------------------------

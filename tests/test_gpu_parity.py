@@ -35,12 +35,12 @@ def _check_frame(pkg, orc, projector, xyzw, rgba, P, W, H, filtered=True):
     return ref
 
 
-@pytest.fixture(params=[2, 1, 0], ids=["tile", "compact", "two-pass"])
+@pytest.fixture(params=[1, 0], ids=["tile", "two-pass"])
 def mode(request, projector):
     projector.set_option("mode", request.param)
     projector.set_option("keep_accum", 1)
     yield request.param
-    projector.set_option("mode", 2)
+    projector.set_option("mode", 1)
     projector.set_option("keep_accum", 0)
 
 
@@ -161,7 +161,7 @@ def test_two_shards_with_external_min_sum(pkg, orc):
     P = pkg.orbit_projection(300, W, H)
     ref = orc.project(xyzw, rgba, P, W, H)
     reff = orc.filter(ref["depth_bits"], ref["img"])
-    for mode in (2, 0):
+    for mode in (1, 0):
         locs = []
         for r in range(2):
             lo, hi = pkg.shard_range(n, r, 2)

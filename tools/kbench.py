@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scenes", default="room_shell,uniform_box")
-    ap.add_argument("--options", default="mode=0;mode=1;mode=2")
+    ap.add_argument("--options", default="mode=0;mode=1")
     ap.add_argument("--filter", type=int, default=1)
     args = ap.parse_args()
     pkg = entry.load_package()
