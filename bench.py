@@ -8,8 +8,11 @@ A "step" is one frame of BASELINE.json config C3: a 100 M-point synthetic cloud 
 to 1920x1080 (clear, min-depth pass, accumulate pass, resolve) plus the depth-heuristic
 prefilter, one distinct camera pose of the orbit trajectory per frame.  The cloud is
 synthesised on-device before the timed region (inputs resident in HBM).  With N > 1 the
-same 100 M points are sharded in contiguous slices over the ranks (config C4: strong
-scaling) and the depth / accumulator buffers are MIN / SUM all-reduced over RCCL.
+cloud is sharded in contiguous point slices over the ranks and the depth / accumulator
+buffers are MIN / SUM all-reduced over RCCL: by default every rank keeps 100 M points
+(N x 100 M in total, "scaling": "weak" -- per-frame pixel work and the exchanged buffers
+do not shrink with N, so a fixed 100 M-point cloud split 8 ways, `--scaling strong` =
+BASELINE config C4, is bound by them, not by the projector).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
@@ -39,8 +42,15 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="room_shell", choices=["uniform_box", "room_shell"])
     ap.add_argument("--no-filter", action="store_true", help="projection only (config C2 style)")
-    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
-                    help="N>1: strong = --points total (BASELINE C4), weak = --points per GPU")
+    ap.add_argument("--scaling", default="weak", choices=["strong", "weak"],
+                    help="N>1: weak = --points per GPU (default; C5-style growth), strong = --points total (BASELINE C4)")
+    ap.add_argument("--colour", default="reduce_scatter", choices=["allreduce", "reduce_scatter"],
+                    help="N>1: how the colour accumulators are merged (see sharded.py)")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
+                    help="N>1: frames in flight per rank (2 = frame k's RCCL exchange overlaps frame k+1's kernels)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="rehearsal on ONE GPU: run the N>1 code path (streams, RCCL collectives in a 1-rank "
+                         "group, 2 frames in flight); the numbers are not a benchmark result")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=10_000_000)
     ap.add_argument("--cpu-frames", type=int, default=0, help="0 = pick so the leg takes about 10-20 s")
@@ -95,33 +105,75 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_exchange  # take the exchange code path
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29555")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     pkg = entry.load_package()
     W, H = args.width, args.height
     total = args.points * (world if args.scaling == "weak" else 1)
     lo, hi = pkg.shard_range(total, rank, world)
-    proj = pkg.Projector(local_rank)
-    proj.generate_synthetic(args.scene, SEEDS["C3"], lo, hi - lo, total)
-    proj.set_resolution(W, H)
     with_filter = not args.no_filter
-
-    local = pkg.sharded.HipLocal(proj)
-    if world > 1:
-        local.bind_stream()  # kernels and RCCL collectives ordered on torch's current stream
-    sharded = pkg.ShardedProjector(local)
     poses = [pkg.orbit_projection(k, W, H) for k in range(args.warmup + args.steps)]
 
+    # one context per frame in flight: with N > 1 two frames alternate between two contexts on
+    # two HIP streams, so the RCCL exchange of frame k overlaps the kernels of frame k + 1
+    depth_k = args.pipeline if multi else 1
+    projs, locals_, streams = [], [], []
+    for j in range(depth_k):
+        pj = pkg.Projector(local_rank)
+        pj.generate_synthetic(args.scene, SEEDS["C3"], lo, hi - lo, total)
+        pj.set_resolution(W, H)
+        lj = pkg.sharded.HipLocal(pj)
+        st = torch.cuda.Stream(device=local_rank) if multi else None
+        if st is not None:
+            with torch.cuda.stream(st):
+                lj.bind_stream()  # kernels and RCCL collectives ordered on this stream
+        projs.append(pj), locals_.append(lj), streams.append(st)
+    proj = projs[0]
+
+    def make_renderers(colour):
+        return [pkg.ShardedProjector(lj, colour=colour, force_exchange=args.force_exchange) for lj in locals_]
+
     def sync():
-        proj.synchronize()
+        for pj in projs:
+            pj.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
 
-    # parity gate on pose 0 at full size: single-GPU / sharded result vs the oracle run
-    # on the host (bounded: only when the cloud is small enough to regenerate on the CPU)
+    def render(renderers, k, P):
+        j = k % depth_k
+        if streams[j] is None:
+            renderers[j].render(P, with_filter)
+        else:
+            with torch.cuda.stream(streams[j]):
+                renderers[j].render(P, with_filter)
+
+    # N > 1: check the configured colour form against the plain all-reduce form on pose 0 and
+    # fall back (on every rank) if any rank sees a difference
+    colour = args.colour if multi else "allreduce"
+    if multi and colour != "allreduce":
+        ok = 1
+        try:
+            ref_r, new_r = make_renderers("allreduce"), make_renderers(colour)
+            render(ref_r, 0, poses[0]); sync()
+            ref_img = locals_[0].image_tensor().clone()
+            render(new_r, 0, poses[0]); sync()
+            ok = int(torch.equal(ref_img, locals_[0].image_tensor()))
+        except Exception as exc:  # noqa: BLE001
+            print("rank %d: colour form %s failed (%s), falling back" % (rank, colour, exc), file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            colour = "allreduce"
+    renderers = make_renderers(colour)
+
+    # parity gate on pose 0 at full size vs the oracle run on the host (bounded: only when
+    # the cloud is small enough to regenerate on the CPU)
     parity = None
     if rank == 0 and not args.no_parity and world == 1 and total <= 20_000_000:
         orc = entry.load_oracle()
@@ -132,19 +184,24 @@ def main():
         del xyzw, rgba
 
     for k in range(args.warmup):
-        sharded.render(poses[k], with_filter)
+        render(renderers, k, poses[k])
     sync()
-    proj.timing_enable(True)
-    proj.timing_reset()
+    for pj in projs:
+        pj.timing_enable(True)
+        pj.timing_reset()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        sharded.render(poses[args.warmup + k], with_filter)
+        render(renderers, k, poses[args.warmup + k])
     sync()
     dt = time.perf_counter() - t0
-    timing = proj.timing()
-    proj.timing_enable(False)
+    timing = {}
+    for pj in projs:
+        for name, (ms, cnt) in pj.timing().items():
+            a, b2 = timing.get(name, (0.0, 0))
+            timing[name] = (a + ms, b2 + cnt)
+        pj.timing_enable(False)
 
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -179,8 +236,8 @@ def main():
                                    % (total, args.scene, W, H, " + depth-heuristic prefilter" if with_filter else ""),
                        "points_total": total, "points_per_gpu": n_local, "scene": args.scene,
                        "resolution": [W, H], "prefilter": with_filter,
-                       "parallelism": "point-shard x%d, RCCL all-reduce MIN(depth)+SUM(accum)" % world
-                       if world > 1 else "single GPU"},
+                       "parallelism": ("point-shard x%d, RCCL all-reduce MIN(depth) + %s SUM(accum), %d frames in "
+                                       "flight" % (world, colour, depth_k)) if multi else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": 12.0 * n_local, "avg_launch_ms": dom_ms},
@@ -191,8 +248,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(entry.load_oracle(), pkg, args)
         print(json.dumps(out))
-    proj.close()
-    if world > 1:
+    for pj in projs:
+        pj.close()
+    if multi:
         dist.destroy_process_group()
 
 

@@ -121,6 +121,10 @@ int rtr_clear(rtr_ctx *ctx);                           /* render.cu:16-31 + proj
 int rtr_min_depth_pass(rtr_ctx *ctx, const float P[16]);  /* render.cu:53-83   */
 int rtr_accumulate_pass(rtr_ctx *ctx, const float P[16]); /* render.cu:85-130  */
 int rtr_resolve(rtr_ctx *ctx);                         /* render.cu:132-163 */
+/* Resolve only pixels [first_pixel, first_pixel + count) (first_pixel % 4 == 0) into
+ * RTR_BUF_IMAGE, reading the accumulators either from RTR_BUF_ACCUM (acc_dev NULL) or from
+ * a caller-owned device array of count*4 u32 -- the slice a reduce-scatter hands to a rank. */
+int rtr_resolve_range(rtr_ctx *ctx, const void *acc_dev, uint64_t first_pixel, uint64_t count);
 int rtr_filter(rtr_ctx *ctx);                          /* project_cloud.cu:331-392 */
 
 /* ---- 6. device-resident buffers (owned by the context, valid until the next

@@ -566,6 +566,18 @@ int rtr_resolve(rtr_ctx *c) {
     return launch_check(c, "resolve");
 }
 
+int rtr_resolve_range(rtr_ctx *c, const void *acc_dev, uint64_t first_pixel, uint64_t count) {
+    if (!c) return RTR_ERR_INVALID;
+    if (int rc = check_frame(c)) return rc;
+    const uint64_t npix = (uint64_t)c->W * c->H;
+    NEED(c, first_pixel % 4 == 0 && first_pixel + count <= npix, "bad pixel range (first must be a multiple of 4)");
+    if (count == 0) return RTR_OK;
+    DevGuard g(c->device);
+    const uint32_t *src = acc_dev ? static_cast<const uint32_t *>(acc_dev) : c->acc + first_pixel * 4;
+    { Timed t(c, RTR_K_RESOLVE); rtr::launch_resolve(c->stream, src, c->img + first_pixel * 3, (size_t)count); }
+    return launch_check(c, "resolve_range");
+}
+
 int rtr_filter(rtr_ctx *c) {
     if (!c) return RTR_ERR_INVALID;
     if (int rc = check_frame(c)) return rc;

@@ -151,6 +151,9 @@ class Projector:
     def filter(self):
         self._chk(self._lib.rtr_filter(self._ctx))
 
+    def resolve_range(self, first_pixel, count, acc_dev_ptr=None):
+        self._chk(self._lib.rtr_resolve_range(self._ctx, C.c_void_p(acc_dev_ptr or 0), first_pixel, count))
+
     # -- buffers
     _BUF = {L.BUF_DEPTH: (np.uint32, "<u4", lambda w, h: (h, w)),
             L.BUF_ACCUM: (np.uint32, "<u4", lambda w, h: (h, w, 4)),

@@ -191,3 +191,33 @@ def test_two_shards_with_external_min_sum(pkg, orc):
             assert np.array_equal(loc.p.download(pkg._lib.BUF_DEPTH), reff["depth"].view(np.uint32))
             assert np.array_equal(loc.p.download(pkg._lib.BUF_TENSOR).reshape(5, H, W), reff["tensor"])
             loc.p.close()
+
+
+def test_4k_frame_uses_wide_tiles(pkg, orc, projector, mode):
+    """3840x2160 (config C5 resolution): 64x32 tiles in the binned mode, H % 16 == 0."""
+    n, W, H = 300_000, 3840, 2160
+    xyzw, rgba = orc.generate("room_shell", 0xC0FFEE05, 0, n, n)
+    _check_frame(pkg, orc, projector, xyzw, rgba, pkg.orbit_projection(7, W, H), W, H)
+
+
+def test_odd_resolution_projection_only(pkg, orc, projector, mode):
+    """W, H not multiples of the tile or of 4: ragged tiles and unaligned image rows."""
+    n, W, H = 80_000, 333, 131
+    xyzw, rgba = orc.generate("uniform_box", 4, 0, n, n)
+    _check_frame(pkg, orc, projector, xyzw, rgba, pkg.orbit_projection(11, W, H), W, H, filtered=False)
+
+
+def test_hot_pixel_and_hot_tile(pkg, orc, projector, mode):
+    """Half a million points in ONE pixel plus a dense 20x20 pixel patch: one workgroup owns
+    the whole load in the binned mode, the atomics pile up on one address in mode 0."""
+    rng = np.random.default_rng(9)
+    n_hot, n_patch = 500_000, 300_000
+    hot = np.tile(np.array([[0.0, 0.0, 2.0]], np.float32), (n_hot, 1))
+    hot[:, 2] += rng.uniform(0, 0.05, n_hot).astype(np.float32)  # straddles the 2 cm window
+    patch = np.stack([rng.uniform(0.1, 0.3, n_patch), rng.uniform(0.1, 0.3, n_patch),
+                      rng.uniform(1.9, 2.1, n_patch)], axis=1).astype(np.float32)
+    xyz = np.concatenate([hot, patch])
+    rgb = rng.integers(0, 256, size=(len(xyz), 3), dtype=np.uint8)
+    xyzw, rgba = cloud(xyz, rgb)
+    ref = _check_frame(pkg, orc, projector, xyzw, rgba, kat_P(orc), 64, 48)
+    assert ref["acc"][24, 32, 3] > 100_000
