@@ -8,6 +8,7 @@ from ._lib import RtrError, RtrParams, build, LIB_PATH, SYMBOLS, EMPTY_DEPTH
 from .camera import CameraCalibration, compose_projection, benchmark_calibration, orbit_pose, orbit_projection
 from .projector import Projector, ProjectCloud, DeviceBuffer
 from .sharded import ShardedProjector, shard_range
+from . import formats, sharded
 
 __all__ = ["RtrError", "RtrParams", "build", "LIB_PATH", "SYMBOLS", "EMPTY_DEPTH", "CameraCalibration",
            "compose_projection", "benchmark_calibration", "orbit_pose", "orbit_projection", "Projector",

@@ -205,6 +205,12 @@ class ProjectCloud:
         self._p.upload_points(vertices, colors)
         self.modelFilename = modelFilename
 
+    @classmethod
+    def from_grid(cls, grid, modelFilename="", device=0):
+        """The reference constructor's argument: a block grid (project_cloud.cu:189-206);
+        `grid` is a formats.Grid (CloudReader::loadCloud's result, cloudreader.cpp:180-216)."""
+        return cls(grid.vertex_positions(), grid.vertex_colors(), modelFilename, device)
+
     @property
     def projector(self):
         return self._p

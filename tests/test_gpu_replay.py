@@ -1,0 +1,65 @@
+"""-m gpu: trajectory replay CLI (tools/render_trajectory.py, the reference's
+example/render_trajectory/main.cpp): .ply + COLMAP cameras.txt / images.txt -> frames that
+match the oracle; also the TUM-style trajectory the reference's code actually parses."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _read_ppm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"P6"
+        w, h = (int(v) for v in f.readline().split())
+        f.readline()
+        return np.frombuffer(f.read(), np.uint8).reshape(h, w, 3)
+
+
+def _read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"Pf"
+        w, h = (int(v) for v in f.readline().split())
+        f.readline()
+        return np.frombuffer(f.read(), np.float32).reshape(h, w)[::-1]
+
+
+@pytest.mark.parametrize("traj_kind,filtered", [("colmap", False), ("tum", True)])
+def test_replay_cli_matches_oracle(pkg, orc, tmp_path, traj_kind, filtered):
+    F = pkg.formats
+    n, W, H = 60_000, 640, 480
+    xyzw, rgba = orc.generate("room_shell", 0xC0FFEE05, 0, n, n)
+    F.write_ply(tmp_path / "cloud.ply", xyzw[:, :3], rgba[:, :3])
+    cal = pkg.benchmark_calibration(W, H)
+    F.write_cameras_txt(tmp_path / "cameras.txt", cal)
+    poses = [pkg.orbit_pose(k) for k in (0, 111, 222, 333)]
+    if traj_kind == "colmap":
+        traj = tmp_path / "images.txt"
+        F.write_images_txt(traj, poses)
+        poses_back = [E for E, _ in F.read_trajectory_colmap(traj)]
+    else:
+        traj = tmp_path / "traj.txt"
+        F.write_trajectory_tum(traj, poses)
+        poses_back = F.read_trajectory_tum(traj)
+    out = tmp_path / "frames"
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "render_trajectory.py"), str(tmp_path / "cloud.ply"), str(traj),
+           str(tmp_path / "cameras.txt"), "--out", str(out), "--every", "1"] + (["--filtered"] if filtered else [])
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    assert "Loaded %d points" % n in res.stdout
+    cal_back = F.load_calibration(tmp_path / "cameras.txt")
+    bgra = np.ascontiguousarray(rgba[:, [2, 1, 0, 3]])  # the loader stores B,G,R (cloudreader.cpp:168)
+    for k, E in enumerate(poses_back):
+        P = orc.compose_projection(cal_back.getIntrinsicsMatrix(), E)
+        ref = orc.project(xyzw, bgra, P, W, H)
+        img, depth = ref["img"], ref["depth_bits"].view(np.float32)
+        if filtered:
+            rf = orc.filter(ref["depth_bits"], ref["img"])
+            img, depth = rf["img"], rf["depth"]
+        assert np.array_equal(_read_ppm(out / ("frame_%d.ppm" % (k + 1))), img[:, :, ::-1])
+        assert np.array_equal(_read_pfm(out / ("frame_%d.pfm" % (k + 1))).view(np.uint32), depth.view(np.uint32))
