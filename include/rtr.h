@@ -69,12 +69,17 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          accumulate + resolve (no global atomics on the frame buffers); 0 = the
  *          reference's structure: two full passes with atomicMin / atomicAdd
  *          (render.cu:53-130).
+ *  "cull": 1 = skip 256-point chunks whose bounding box is provably outside the frustum
+ *          (exact: same frame; an algorithmic byte reduction, off by default and reported
+ *          separately from the roofline figure; needs a spatially coherent point order).
  *  "keep_accum": 1 = the whole-frame calls also write RTR_BUF_ACCUM (default 0; the phase
  *          calls always do). */
 int rtr_set_option(rtr_ctx *ctx, const char *key, int value);
-/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the
- * context's own stream; NULL restores the private stream. */
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's
+ * own non-blocking stream; NULL means HIP's default stream.  rtr_reset_stream returns to the
+ * private stream. */
 int rtr_set_stream(rtr_ctx *ctx, void *hip_stream);
+int rtr_reset_stream(rtr_ctx *ctx);
 int rtr_synchronize(rtr_ctx *ctx);
 
 /* ---- 2. the resident cloud (project_cloud.cu:191-206) --------------------------- */
@@ -89,6 +94,11 @@ int rtr_upload_points(rtr_ctx *ctx, const float *xyz, size_t xyz_stride_bytes, c
  * HBM (counter-based generator; bit-identical to the oracle's). */
 int rtr_generate_synthetic(rtr_ctx *ctx, int scene, uint64_t seed, uint64_t first, uint64_t count,
                            uint64_t total);
+/* One-off Morton (Z-order) sort of the resident cloud: consecutive points become spatial
+ * neighbours, like the reference loader's 0.25 m block order (cloudreader.cpp:8-82).  Never
+ * changes a frame (min and integer sums commute); it changes rtr_download_points' order and
+ * makes the tile sort cheap and option "cull" effective. */
+int rtr_reorder_points(rtr_ctx *ctx);
 int rtr_num_points(const rtr_ctx *ctx, uint64_t *n);
 /* Copies the resident cloud back as float4 / uchar4 AoS (tests, debugging). */
 int rtr_download_points(rtr_ctx *ctx, float *xyzw, uint8_t *rgba, uint64_t first, uint64_t count);

@@ -18,7 +18,7 @@ SYMBOLS = [
     "rtr_num_points", "rtr_download_points", "rtr_compose_projection", "rtr_set_resolution", "rtr_project",
     "rtr_project_filtered", "rtr_render", "rtr_clear", "rtr_min_depth_pass", "rtr_accumulate_pass", "rtr_resolve",
     "rtr_filter", "rtr_device_buffer", "rtr_download_buffer", "rtr_timing_enable", "rtr_timing_reset",
-    "rtr_timing_get", "rtr_set_option", "rtr_stream_probe", "rtr_resolve_range",
+    "rtr_timing_get", "rtr_set_option", "rtr_stream_probe", "rtr_resolve_range", "rtr_reorder_points", "rtr_reset_stream",
 ]
 
 RTR_OK, RTR_ERR_INVALID, RTR_ERR_HIP, RTR_ERR_NO_OUTPUT, RTR_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
@@ -69,6 +69,7 @@ def lib():
     L.rtr_set_params.argtypes = [vp, C.POINTER(RtrParams)]
     L.rtr_get_params.argtypes = [vp, C.POINTER(RtrParams)]
     L.rtr_set_stream.argtypes = [vp, vp]
+    L.rtr_reset_stream.argtypes = [vp]
     L.rtr_synchronize.argtypes = [vp]
     L.rtr_upload_points.argtypes = [vp, vp, sz, vp, sz, sz]
     L.rtr_generate_synthetic.argtypes = [vp, i32, u64, u64, u64, u64]
@@ -84,6 +85,7 @@ def lib():
     L.rtr_accumulate_pass.argtypes = [vp, vp]
     L.rtr_resolve.argtypes = [vp]
     L.rtr_filter.argtypes = [vp]
+    L.rtr_reorder_points.argtypes = [vp]
     L.rtr_resolve_range.argtypes = [vp, vp, u64, u64]
     L.rtr_device_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz)]
     L.rtr_download_buffer.argtypes = [vp, i32, vp, sz]

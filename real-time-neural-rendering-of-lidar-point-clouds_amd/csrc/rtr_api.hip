@@ -28,6 +28,7 @@ struct rtr_ctx {
     // resident cloud (SoA)
     float *x = nullptr, *y = nullptr, *z = nullptr;
     uint32_t *rgba = nullptr;
+    float *bounds = nullptr;    // bounding box per 256-point chunk (frustum culling option)
     uint64_t n = 0, cap = 0;
 
     // frame buffers
@@ -50,6 +51,7 @@ struct rtr_ctx {
                                 // 1 = tile-binned LDS z-buffer (default)
     int opt_keep_accum = 0;     // whole-frame calls also materialise RTR_BUF_ACCUM
     int opt_probe = 0;          // rtr_stream_probe variant (experiments)
+    int opt_cull = 0;           // per-chunk frustum culling in T1
 
     // timing
     bool timing = false;
@@ -113,7 +115,7 @@ void free_lists(rtr_ctx *c) {
 }
 
 void free_cloud(rtr_ctx *c) {
-    dfree(c->x); dfree(c->y); dfree(c->z); dfree(c->rgba);
+    dfree(c->x); dfree(c->y); dfree(c->z); dfree(c->rgba); dfree(c->bounds);
     free_lists(c);
     c->n = c->cap = 0;
 }
@@ -157,6 +159,7 @@ int alloc_cloud(rtr_ctx *c, uint64_t n) {
         HIP_TRY(c, hipMalloc((void **)&c->y, n_pad * 4));
         HIP_TRY(c, hipMalloc((void **)&c->z, n_pad * 4));
         HIP_TRY(c, hipMalloc((void **)&c->rgba, n_pad * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->bounds, ((n_pad / 4 + 63) / 64) * 6 * sizeof(float)));
         c->cap = n_pad;
     }
     c->n = n;
@@ -324,6 +327,10 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
         rtr::set_point_grid(value);
         return RTR_OK;
     }
+    if (!strcmp(key, "cull")) {
+        c->opt_cull = value != 0;
+        return RTR_OK;
+    }
     if (!strcmp(key, "debug_skip")) {  // timing experiments only: the frame becomes wrong
         rtr::set_debug_skip(value);
         return RTR_OK;
@@ -354,13 +361,22 @@ int rtr_get_params(const rtr_ctx *c, rtr_params *p) {
     return RTR_OK;
 }
 
-int rtr_set_stream(rtr_ctx *c, void *s) {
-    if (!c) return RTR_ERR_INVALID;
+static int switch_stream(rtr_ctx *c, hipStream_t s) {
     DevGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     (void)collect_timing(c);
-    c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+    c->stream = s;
     return RTR_OK;
+}
+
+int rtr_set_stream(rtr_ctx *c, void *s) {  // NULL is HIP's default stream, a valid choice
+    if (!c) return RTR_ERR_INVALID;
+    return switch_stream(c, reinterpret_cast<hipStream_t>(s));
+}
+
+int rtr_reset_stream(rtr_ctx *c) {
+    if (!c) return RTR_ERR_INVALID;
+    return switch_stream(c, c->own_stream);
 }
 
 int rtr_synchronize(rtr_ctx *c) {
@@ -398,6 +414,7 @@ int rtr_upload_points(rtr_ctx *c, const float *xyz, size_t xs, const uint8_t *rg
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     rtr::launch_pad_nan(c->stream, c->x, c->y, c->z, c->rgba, n, (n + 3) & ~3ull);
+    rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     dfree(sx); dfree(sc);
     return launch_check(c, "aos_to_soa");
@@ -414,8 +431,21 @@ int rtr_generate_synthetic(rtr_ctx *c, int scene, uint64_t seed, uint64_t first,
     if (rc) return rc;
     rtr::launch_generate(c->stream, scene, seed, first, count, total, c->x, c->y, c->z, c->rgba);
     rtr::launch_pad_nan(c->stream, c->x, c->y, c->z, c->rgba, count, (count + 3) & ~3ull);
+    rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return launch_check(c, "generate");
+}
+
+int rtr_reorder_points(rtr_ctx *c) {
+    if (!c) return RTR_ERR_INVALID;
+    DevGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->list_valid = false;
+    int e = rtr::reorder_morton(c->stream, c->x, c->y, c->z, c->rgba, c->n);
+    if (e != 0) return fail(c, RTR_ERR_HIP, "reorder failed: %s", hipGetErrorString((hipError_t)e));
+    rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return launch_check(c, "reorder");
 }
 
 int rtr_num_points(const rtr_ctx *c, uint64_t *n) {
@@ -510,7 +540,8 @@ static int bin_points(rtr_ctx *c, const float P[16]) {
     if (int rc = ensure_tiles(c)) return rc;
     {
         Timed t(c, RTR_K_MIN_DEPTH);
-        rtr::launch_project_bin(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->lists, c->bins.tile_hist);
+        rtr::launch_project_bin(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->lists, c->bins.tile_hist,
+                                c->opt_cull ? c->bounds : nullptr);
     }
     {
         Timed t(c, RTR_K_BIN);

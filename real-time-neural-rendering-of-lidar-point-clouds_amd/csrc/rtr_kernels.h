@@ -51,8 +51,11 @@ void set_point_grid(int blocks);       // grid of the point kernels (tuning; inv
 uint64_t list_region_cap(uint64_t n);  // entries per wave region
 uint64_t list_num_waves(uint64_t n);   // number of wave regions
 int tile_count(int W, int H);
+// bounds != NULL enables per-chunk frustum culling (see k_project_bin)
 void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const Lists &L,
-                        uint32_t *tile_hist);
+                        uint32_t *tile_hist, const float *bounds);
+void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds);  // 6 floats per 256 points
+int reorder_morton(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, uint64_t n);  // rtr_reorder.hip
 void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const Lists &L, const Bins &B);
 void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const Bins &B, float window, uint32_t *depth,
                  uint32_t *acc, uint8_t *img, int write_acc);

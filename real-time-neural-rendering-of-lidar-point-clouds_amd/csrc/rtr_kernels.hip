@@ -346,9 +346,21 @@ uint64_t list_num_waves(uint64_t n) {
 //      underflow enters the argument.  Skip the quad if no lane may be inside;
 //   3. the exact contract arithmetic (reciprocal, rintf, range test) for what is left.
 // Spatially coherent clouds (LiDAR block order) take the early exits for ~90 % of the waves.
+//
+// CULL (option "cull", off by default, reported separately from the roofline figure): each
+// wave first tests the bounding box of its 256-point chunk (k_chunk_bounds, 24 B per chunk)
+// against the five frustum half-spaces r.z >= 0, r.x + r.z >= 0, W r.z - r.x >= 0,
+// r.y + r.z >= 0, H r.z - r.y >= 0 -- supersets of the exact acceptance region (a kept point
+// has its fp32 quotient in [-0.5, W - 0.5], up to 2^-22 relative) -- and skips the chunk,
+// loads included, when the box lies entirely on the wrong side of one of them by more than
+// 1e-4 x the magnitude of the terms involved (the fp32 evaluation of r.x, r.y, r.z errs by
+// < 3e-7 x that magnitude, so no point the exact arithmetic would keep is ever skipped).
+// Only spatially coherent point orders have tight chunk boxes (rtr_reorder_points).
+template <bool CULL>
 __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
                                                         const float4 *__restrict__ z4, uint64_t n4, Proj P, int W,
-                                                        int H, TileGeom g, Lists L, uint32_t *__restrict__ tile_hist) {
+                                                        int H, TileGeom g, Lists L, uint32_t *__restrict__ tile_hist,
+                                                        const float *__restrict__ bounds) {
     extern __shared__ uint32_t s_hist[];
     for (int t = threadIdx.x; t < g.ntiles; t += kBlock) s_hist[t] = 0;
     __syncthreads();
@@ -361,7 +373,9 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
     const uint64_t base = (gtid >> 6) * L.region_cap;
     uint32_t *__restrict__ my_t = L.tiled + base, *__restrict__ my_d = L.depth + base, *__restrict__ my_i = L.idx + base;
     uint32_t fill = 0;
-    for (uint64_t i = gtid; i < n4; i += stride) {
+
+    // one quad (four points per lane) of the wave; every exit is wave-uniform
+    auto do_quad = [&](uint64_t i) {
         float4 X = ld_stream(x4 + i), Y = ld_stream(y4 + i), Z = ld_stream(z4 + i);
         const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
         float rz[4];
@@ -371,7 +385,7 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
             rz[k] = f_add(fmaf(P.m[10], zs[k], fmaf(P.m[9], ys[k], f_mul(P.m[8], xs[k]))), P.m[11]);
             front = front || (rz[k] > 0.0f);  // render.cu:63 (NaN fails)
         }
-        if (__ballot(front) == 0ull) continue;
+        if (__ballot(front) == 0ull) return;
         float rx[4], ry[4];
         bool maybe[4], any = false;
 #pragma unroll
@@ -383,7 +397,7 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
             maybe[k] = (z > 0.0f) && !out;
             any = any || maybe[k];
         }
-        if (__ballot(any) == 0ull) continue;
+        if (__ballot(any) == 0ull) return;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             unsigned long long mm = __ballot(maybe[k]);
@@ -406,6 +420,59 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
                 lds_hist_add(s_hist, tile, true);  // exec = the in-frustum lanes
             }
             fill += (uint32_t)__popcll(m);
+        }
+    };
+
+    if (!CULL) {
+        for (uint64_t i = gtid; i < n4; i += stride) do_quad(i);
+    } else {
+        // The wave owns chunks wave, wave + NW, wave + 2 NW, ... (the same grid-stride order as
+        // above).  64 of them are tested at once, one per lane, then only the survivors are
+        // streamed: the box test costs 1/64 and its load latency is paid once per 64 chunks.
+        const uint64_t nchunks = (n4 + 63) / 64, NW = stride >> 6, wave = gtid >> 6;
+        float pl[5][4], plm[5][3], pld[5];  // half-space coefficients, |coefficients| row sums, |offset| sums
+        {
+            const float comb[5][3] = {{0.f, 0.f, 1.f}, {1.f, 0.f, 1.f}, {-1.f, 0.f, fW}, {0.f, 1.f, 1.f}, {0.f, -1.f, fH}};
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pl[q][k] = comb[q][0] * P.m[k] + comb[q][1] * P.m[4 + k] + comb[q][2] * P.m[8 + k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    plm[q][k] = fabsf(comb[q][0] * P.m[k]) + fabsf(comb[q][1] * P.m[4 + k]) + fabsf(comb[q][2] * P.m[8 + k]);
+                pld[q] = fabsf(comb[q][0] * P.m[3]) + fabsf(comb[q][1] * P.m[7]) + fabsf(comb[q][2] * P.m[11]);
+            }
+        }
+        for (uint64_t g0 = 0;; g0 += 64) {
+            const uint64_t chunk = wave + (g0 + lane) * NW;
+            const bool valid = chunk < nchunks;
+            if (__ballot(valid) == 0ull) break;
+            bool keep = false;
+            if (valid) {
+                const float *b = bounds + 6 * chunk;
+                const float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
+                bool culled = false;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    float v = pl[q][3], m = pld[q];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        float t0 = pl[q][k] * lo[k], t1 = pl[q][k] * hi[k];
+                        v += t0 > t1 ? t0 : t1;
+                        float e0 = fabsf(lo[k]), e1 = fabsf(hi[k]);
+                        m += plm[q][k] * (e0 > e1 ? e0 : e1);
+                    }
+                    culled = culled || (v < -1e-4f * m);  // NaN / inf boxes compare false: never culled
+                }
+                keep = !culled;
+            }
+            unsigned long long mask = __ballot(keep);
+            while (mask) {
+                const int l = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const uint64_t i = (wave + (g0 + l) * NW) * 64 + lane;
+                if (i < n4) do_quad(i);
+            }
         }
     }
     if (lane == 0) L.counts[gtid >> 6] = fill;
@@ -639,12 +706,62 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__
 }
 
 void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const Lists &L,
-                        uint32_t *tile_hist) {
+                        uint32_t *tile_hist, const float *bounds) {
     TileGeom g = tile_geom(W, H);
     uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) return;
-    hipLaunchKernelGGL(k_project_bin, dim3(point_grid(n4)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s,
-                       (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, g, L, tile_hist);
+    if (bounds)
+        hipLaunchKernelGGL(k_project_bin<true>, dim3(point_grid(n4)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s,
+                           (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, g, L, tile_hist,
+                           bounds);
+    else
+        hipLaunchKernelGGL(k_project_bin<false>, dim3(point_grid(n4)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s,
+                           (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, g, L, tile_hist,
+                           bounds);
+}
+
+// bounding box of every 256-point chunk (the unit one wave of T1 handles per iteration):
+// bounds[6 c .. 6 c + 5] = min x, y, z, max x, y, z; NaN padding is ignored.
+__global__ __launch_bounds__(kBlock) void k_chunk_bounds(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
+                                                         const float4 *__restrict__ z4, uint64_t n4,
+                                                         float *__restrict__ bounds) {
+    const uint64_t nchunks = (n4 + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const float inf = __uint_as_float(0x7F800000u);
+    for (uint64_t c = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6; c < nchunks;
+         c += ((uint64_t)gridDim.x * kBlock) >> 6) {
+        float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+        uint64_t i = c * 64 + lane;
+        if (i < n4) {
+            const float4 v[3] = {x4[i], y4[i], z4[i]};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = fminf(fminf(v[k].x, v[k].y), fminf(fminf(v[k].z, v[k].w), lo[k]));  // fminf ignores NaN
+                hi[k] = fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(fmaxf(v[k].z, v[k].w), hi[k]));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+            }
+        }
+        if (lane == 0) {
+            float *b = bounds + 6 * c;
+            b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2];
+            b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
+        }
+    }
+}
+
+void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds) {
+    uint64_t n4 = (c.n + 3) / 4;
+    if (n4 == 0) return;
+    uint64_t blocks = ((n4 + 63) / 64 + 3) / 4;
+    hipLaunchKernelGGL(k_chunk_bounds, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kBlock), 0, s,
+                       (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, bounds);
 }
 
 void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const Lists &L, const Bins &B) {

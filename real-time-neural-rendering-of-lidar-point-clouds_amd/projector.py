@@ -60,7 +60,11 @@ class Projector:
         self._chk(self._lib.rtr_synchronize(self._ctx))
 
     def set_stream(self, hip_stream_ptr):
+        """Run on the given hipStream_t handle (0 / None = HIP's default stream)."""
         self._chk(self._lib.rtr_set_stream(self._ctx, C.c_void_p(hip_stream_ptr or 0)))
+
+    def reset_stream(self):
+        self._chk(self._lib.rtr_reset_stream(self._ctx))
 
     @property
     def params(self):
@@ -96,6 +100,10 @@ class Projector:
     def generate_synthetic(self, scene, seed, first, count, total):
         sc = L.SCENES[scene] if isinstance(scene, str) else int(scene)
         self._chk(self._lib.rtr_generate_synthetic(self._ctx, sc, seed, first, count, total))
+
+    def reorder_points(self):
+        """One-off Morton sort of the resident cloud (never changes a frame)."""
+        self._chk(self._lib.rtr_reorder_points(self._ctx))
 
     @property
     def num_points(self):

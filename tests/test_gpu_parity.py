@@ -221,3 +221,61 @@ def test_hot_pixel_and_hot_tile(pkg, orc, projector, mode):
     xyzw, rgba = cloud(xyz, rgb)
     ref = _check_frame(pkg, orc, projector, xyzw, rgba, kat_P(orc), 64, 48)
     assert ref["acc"][24, 32, 3] > 100_000
+
+
+def test_reorder_and_chunk_culling_keep_the_frame(pkg, orc, projector):
+    """rtr_reorder_points (Morton sort) and option "cull" (skip 256-point chunks whose box is
+    outside the frustum) are pure speed-ups: frames stay bit-identical, in every pose."""
+    n, W, H = 400_000, 1920, 1080
+    for scene in ("room_shell", "uniform_box"):
+        xyzw, rgba = orc.generate(scene, 77, 0, n, n)
+        projector.upload_points(xyzw, rgba)
+        projector.set_resolution(W, H)
+        refs = {}
+        for k in (0, 130, 610, 875):
+            P = pkg.orbit_projection(k, W, H)
+            ref = orc.project(xyzw, rgba, P, W, H)
+            refs[k] = (P, ref, orc.filter(ref["depth_bits"], ref["img"]))
+        try:
+            for step in ("cull", "reorder+cull", "reorder"):
+                if step == "reorder+cull":
+                    projector.reorder_points()
+                    back, cols = projector.download_points()
+                    key = lambda a, b: np.lexsort(np.concatenate([a.view(np.uint32), b.view(np.uint8)], axis=1).T)  # noqa: E731
+                    assert np.array_equal(back[key(back, cols)], xyzw[key(xyzw, rgba)])  # a permutation
+                projector.set_option("cull", 0 if step == "reorder" else 1)
+                for k, (P, ref, rf) in refs.items():
+                    img, depth = projector.project(P)
+                    assert np.array_equal(depth.view(np.uint32), ref["depth_bits"]), (scene, step, k)
+                    assert np.array_equal(img, ref["img"]), (scene, step, k)
+                    img_f, depth_f = projector.project(P, filtered=True)
+                    assert np.array_equal(depth_f.view(np.uint32), rf["depth"].view(np.uint32))
+                    assert np.array_equal(projector.download(pkg._lib.BUF_TENSOR).reshape(5, H, W), rf["tensor"])
+        finally:
+            projector.set_option("cull", 0)
+
+
+def test_culling_with_extreme_cameras(pkg, orc, projector):
+    """Cameras inside / far outside the cloud, near-degenerate depths: the conservative box test
+    must never drop a point the exact arithmetic keeps."""
+    n, W, H = 200_000, 640, 480
+    xyzw, rgba = orc.generate("room_shell", 5, 0, n, n)
+    projector.upload_points(xyzw, rgba)
+    projector.reorder_points()
+    projector.set_resolution(W, H)
+    projector.set_option("cull", 1)
+    try:
+        cal = pkg.benchmark_calibration(W, H)
+        rng = np.random.default_rng(2)
+        for trial in range(12):
+            E = pkg.orbit_pose(int(rng.integers(0, 1000)))
+            E[:3, 3] += rng.normal(scale=[0.01, 3.0, 30.0][trial % 3], size=3)
+            if trial % 4 == 3:  # camera exactly on a wall: many points with r.z ~ 0
+                E[:3, 3] = -E[:3, :3] @ np.array([-4.0, 0.2, 0.3])
+            P = pkg.compose_projection(cal.getIntrinsicsMatrix(), E)
+            ref = orc.project(xyzw, rgba, P, W, H)
+            img, depth = projector.project(P)
+            assert np.array_equal(depth.view(np.uint32), ref["depth_bits"]), trial
+            assert np.array_equal(img, ref["img"]), trial
+    finally:
+        projector.set_option("cull", 0)

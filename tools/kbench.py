@@ -29,6 +29,8 @@ def main():
         p.generate_synthetic(scene, 0xC0FFEE03, 0, n, n)
         for optset in args.options.split(";"):
             opts = dict(kv.split("=") for kv in optset.split(",") if kv)
+            if opts.pop("reorder", "0") == "1":
+                p.reorder_points()  # one-off; stays for the following option sets of this scene
             for k, v in opts.items():
                 p.set_option(k, int(v))
             for k in range(3):
