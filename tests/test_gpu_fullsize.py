@@ -1,0 +1,93 @@
+"""-m gpu: BASELINE config C3 at FULL size (1e8 points -> 1920x1080 + prefilter).
+
+Direct check: the cloud synthesised on the GPU is downloaded and projected by the multi-thread
+oracle on the host (about a second on the box's cores) and compared bit for bit.  On top, the
+size-independent properties the domain offers: mode 0 == mode 1, chunk culling / Morton reorder
+keep the frame, and a 2-way point split merged by MIN / SUM equals the unsplit frame."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, W, H = 100_000_000, 1920, 1080
+
+
+def _threads():
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return 8
+
+
+@pytest.mark.parametrize("scene", ["room_shell", "uniform_box"])
+def test_c3_full_size_against_oracle(pkg, orc, scene):
+    import torch
+    p = pkg.Projector(0)
+    try:
+        p.generate_synthetic(scene, 0xC0FFEE03, 0, N, N)
+        p.set_resolution(W, H)
+        P = pkg.orbit_projection(17, W, H)
+        img, depth = p.project(P)
+        xyzw, rgba = p.download_points()
+        # the generator itself at full size: spot-check slices against the oracle's
+        for first in (0, 54_321_000, N - 4096):
+            rx, rc = orc.generate(scene, 0xC0FFEE03, first, 4096, N)
+            assert np.array_equal(xyzw[first:first + 4096].view(np.uint32), rx.view(np.uint32))
+            assert np.array_equal(rgba[first:first + 4096], rc)
+        ref = orc.MTProjector(W, H, _threads()).project(xyzw, rgba, P)
+        assert np.array_equal(depth.view(np.uint32), ref["depth_bits"])
+        assert np.array_equal(img, ref["img"])
+        rf = orc.filter(ref["depth_bits"], ref["img"])
+        img_f, depth_f = p.project(P, filtered=True)
+        assert np.array_equal(depth_f.view(np.uint32), rf["depth"].view(np.uint32))
+        assert np.array_equal(img_f, rf["img"])
+        assert np.array_equal(p.download(pkg._lib.BUF_TENSOR).reshape(5, H, W), rf["tensor"])
+        del xyzw, rgba
+        # properties: the other kernel mode, culling and reordering leave the frame unchanged
+        p.set_option("mode", 0)
+        img0, depth0 = p.project(P)
+        assert np.array_equal(img0, img) and np.array_equal(depth0.view(np.uint32), depth.view(np.uint32))
+        p.set_option("mode", 1)
+        p.set_option("cull", 1)
+        img1, depth1 = p.project(P)
+        assert np.array_equal(img1, img) and np.array_equal(depth1.view(np.uint32), depth.view(np.uint32))
+        if scene == "uniform_box":
+            p.reorder_points()
+            img2, depth2 = p.project(P)
+            assert np.array_equal(img2, img) and np.array_equal(depth2.view(np.uint32), depth.view(np.uint32))
+        p.set_option("cull", 0)
+        # 2-way shard + MIN / SUM merge on the device views == the unsplit frame
+        p.set_option("keep_accum", 1)
+        p.render(P)
+        acc_full = torch.as_tensor(p.device_buffer(pkg._lib.BUF_ACCUM, "<i4"), device="cuda").clone()
+        dep_full = torch.as_tensor(p.device_buffer(pkg._lib.BUF_DEPTH, "<i4"), device="cuda").clone()
+        p.synchronize()
+        torch.cuda.synchronize()
+        halves = []
+        for r in range(2):
+            lo, hi = pkg.shard_range(N, r, 2)
+            p.generate_synthetic(scene, 0xC0FFEE03, lo, hi - lo, N)
+            p.clear()
+            p.min_depth_pass(P)
+            p.synchronize()
+            halves.append(torch.as_tensor(p.device_buffer(pkg._lib.BUF_DEPTH, "<i4"), device="cuda").clone())
+        dmin = torch.minimum(halves[0], halves[1])
+        assert torch.equal(dmin, dep_full)
+        acc = torch.zeros_like(acc_full)
+        for r in range(2):
+            lo, hi = pkg.shard_range(N, r, 2)
+            p.generate_synthetic(scene, 0xC0FFEE03, lo, hi - lo, N)
+            p.clear()
+            p.min_depth_pass(P)
+            dview = torch.as_tensor(p.device_buffer(pkg._lib.BUF_DEPTH, "<i4"), device="cuda")
+            p.synchronize()
+            dview.copy_(dmin)
+            torch.cuda.synchronize()
+            p.accumulate_pass(P)
+            p.synchronize()
+            acc += torch.as_tensor(p.device_buffer(pkg._lib.BUF_ACCUM, "<i4"), device="cuda")
+        assert torch.equal(acc, acc_full)
+    finally:
+        p.close()
