@@ -45,6 +45,7 @@ struct rtr_ctx {
     rtr::Bins bins{};
     uint64_t list_n = 0;        // point count the list / bin buffers were sized for
     int tiles_n = 0;            // tile count the histogram buffers were sized for
+    size_t blk_hist_n = 0;      // elements blk_hist was sized for
     bool list_valid = false;    // bins match list_P / current cloud / resolution / window
     float list_P[12] = {0};
     int opt_mode = 1;           // 0 = two-pass global atomics (the reference's structure),
@@ -101,8 +102,8 @@ void free_frame(rtr_ctx *c) {
     c->list_valid = false;
     dfree(c->depth); dfree(c->acc); dfree(c->img); dfree(c->mask); dfree(c->part_min); dfree(c->part_max); dfree(c->tensor);
     for (int i = 1; i <= 8; ++i) dfree(c->lv.lv[i]);
-    dfree(c->bins.tile_hist); dfree(c->bins.tile_start); dfree(c->bins.cursor);
-    c->tiles_n = 0;
+    dfree(c->bins.tile_hist); dfree(c->bins.tile_start); dfree(c->bins.cursor); dfree(c->bins.blk_hist);
+    c->tiles_n = 0; c->blk_hist_n = 0;
     c->lv.lv[0] = nullptr;
     c->W = c->H = 0;
     c->lv_levels = 0;
@@ -539,9 +540,17 @@ static int bin_points(rtr_ctx *c, const float P[16]) {
     if (int rc = ensure_lists(c)) return rc;
     if (int rc = ensure_tiles(c)) return rc;
     {
+        size_t need = (size_t)(rtr::list_num_waves(c->n) / 4 + 1) * (size_t)c->tiles_n;
+        if (!c->bins.blk_hist || c->blk_hist_n != need) {
+            dfree(c->bins.blk_hist);
+            HIP_TRY(c, hipMalloc((void **)&c->bins.blk_hist, need * sizeof(uint32_t)));
+            c->blk_hist_n = need;
+        }
+    }
+    {
         Timed t(c, RTR_K_MIN_DEPTH);
         rtr::launch_project_bin(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->lists, c->bins.tile_hist,
-                                c->opt_cull ? c->bounds : nullptr);
+                                c->bins.blk_hist, c->opt_cull ? c->bounds : nullptr);
     }
     {
         Timed t(c, RTR_K_BIN);
@@ -562,7 +571,7 @@ int rtr_min_depth_pass(rtr_ctx *c, const float P[16]) {
         if (int rc = bin_points(c, P)) return rc;
         Timed t(c, RTR_K_TILE);
         rtr::launch_tile(c->stream, 1, cloud_of(c), c->W, c->H, c->bins, c->prm.depth_window, c->depth, c->acc, c->img,
-                         0);
+                         0, nullptr);
     } else {
         Timed t(c, RTR_K_MIN_DEPTH);
         rtr::launch_min_depth(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->depth);
@@ -581,7 +590,7 @@ int rtr_accumulate_pass(rtr_ctx *c, const float P[16]) {
     if (use_bins) {
         Timed t(c, RTR_K_TILE);
         rtr::launch_tile(c->stream, 2, cloud_of(c), c->W, c->H, c->bins, c->prm.depth_window, c->depth, c->acc, c->img,
-                         1);
+                         1, nullptr);
     } else {
         Timed t(c, RTR_K_ACCUMULATE);
         rtr::launch_accumulate(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->depth, c->acc, c->prm.depth_window);
@@ -609,18 +618,21 @@ int rtr_resolve_range(rtr_ctx *c, const void *acc_dev, uint64_t first_pixel, uin
     return launch_check(c, "resolve_range");
 }
 
-int rtr_filter(rtr_ctx *c) {
-    if (!c) return RTR_ERR_INVALID;
+static int filter_impl(rtr_ctx *c, int pyramid_parts) {
     if (int rc = check_frame(c)) return rc;
     DevGuard g(c->device);
     if (int rc = ensure_pyramid(c)) return rc;
     {
         Timed t(c, RTR_K_FILTER);
         rtr::launch_filter(c->stream, c->lv, c->depth, c->img, c->mask, c->tensor, c->minmax, c->part_min, c->part_max,
-                           c->W, c->H,
-                           c->prm.filter_strength, c->prm.gradient_threshold);
+                           c->W, c->H, c->prm.filter_strength, c->prm.gradient_threshold, pyramid_parts);
     }
     return launch_check(c, "filter");
+}
+
+int rtr_filter(rtr_ctx *c) {
+    if (!c) return RTR_ERR_INVALID;
+    return filter_impl(c, 0);
 }
 
 // ---- whole frames ------------------------------------------------------------------
@@ -637,12 +649,24 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
     if (c->opt_mode == 1) {  // one launch does clear + min + accumulate + resolve per tile
         DevGuard g(c->device);
         if ((rc = bin_points(c, P))) return rc;
+        // with the default four levels the tile kernel also emits the prefilter's pyramid and
+        // min / max partials (F1) while the finished depth tile is still in LDS
+        rtr::TilePyr pyr{};
+        pyr.enable = (with_filter && c->prm.levels == 4) ? 1 : 0;
+        if (pyr.enable) {
+            pyr.L = c->lv;
+            pyr.n_eff_rows = (uint32_t)((c->H >> 4) << 4);
+            pyr.part_min = c->part_min;
+            pyr.part_max = c->part_max;
+        }
         {
             Timed t(c, RTR_K_TILE);
             rtr::launch_tile(c->stream, 0, cloud_of(c), c->W, c->H, c->bins, c->prm.depth_window, c->depth, c->acc,
-                             c->img, c->opt_keep_accum);
+                             c->img, c->opt_keep_accum, pyr.enable ? &pyr : nullptr);
         }
         if ((rc = launch_check(c, "tile frame"))) return rc;
+        if (with_filter) return filter_impl(c, pyr.enable ? rtr::tile_count(c->W, c->H) : 0);
+        return RTR_OK;
     } else {
         if ((rc = rtr_clear(c))) return rc;
         if ((rc = rtr_min_depth_pass(c, P))) return rc;

@@ -31,12 +31,19 @@ struct Lists {
     uint32_t *counts;               // [num_waves]
     uint64_t region_cap;
 };
+struct TilePyr {  // F1 folded into T4 (whole-frame calls with the default 4 levels)
+    FilterLevels L;
+    uint32_t n_eff_rows;
+    uint32_t *part_min, *part_max;
+    int enable;
+};
 struct Entry {  // 12 bytes, moved with one dwordx3 store
     uint32_t tiled, depth, idx;
 };
 struct Bins {
     Entry *entries;                             // entries counting-sorted by tile
     uint32_t *tile_hist, *tile_start, *cursor;  // [ntiles], [ntiles + 1], [ntiles]
+    uint32_t *blk_hist;                         // [point-grid workgroups][ntiles]: T1's per-workgroup counts
 };
 
 void launch_clear(hipStream_t s, uint32_t *depth, uint32_t *acc, size_t npix);
@@ -53,17 +60,17 @@ uint64_t list_num_waves(uint64_t n);   // number of wave regions
 int tile_count(int W, int H);
 // bounds != NULL enables per-chunk frustum culling (see k_project_bin)
 void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const Lists &L,
-                        uint32_t *tile_hist, const float *bounds);
+                        uint32_t *tile_hist, uint32_t *blk_hist, const float *bounds);
 void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds);  // 6 floats per 256 points
 int reorder_morton(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, uint64_t n);  // rtr_reorder.hip
 void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const Lists &L, const Bins &B);
 void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const Bins &B, float window, uint32_t *depth,
-                 uint32_t *acc, uint8_t *img, int write_acc);
+                 uint32_t *acc, uint8_t *img, int write_acc, const TilePyr *pyr);
 void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *sink, int variant);
 void launch_resolve(hipStream_t s, const uint32_t *acc, uint8_t *img, size_t npix);
 void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, uint8_t *img, uint8_t *mask,
                    uint16_t *tensor, uint32_t *minmax, uint32_t *part_min, uint32_t *part_max, int W, int H,
-                   float strength, float thr);
+                   float strength, float thr, int pyramid_parts);
 void launch_generate(hipStream_t s, int scene, uint64_t seed, uint64_t first, uint64_t count, uint64_t total,
                      float *x, float *y, float *z, uint32_t *rgba);
 void launch_aos_to_soa(hipStream_t s, const uint8_t *xyz, size_t xyz_stride, const uint8_t *rgb, size_t rgb_stride,

@@ -360,6 +360,7 @@ template <bool CULL>
 __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
                                                         const float4 *__restrict__ z4, uint64_t n4, Proj P, int W,
                                                         int H, TileGeom g, Lists L, uint32_t *__restrict__ tile_hist,
+                                                        uint32_t *__restrict__ blk_hist,
                                                         const float *__restrict__ bounds) {
     extern __shared__ uint32_t s_hist[];
     for (int t = threadIdx.x; t < g.ntiles; t += kBlock) s_hist[t] = 0;
@@ -477,8 +478,13 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
     }
     if (lane == 0) L.counts[gtid >> 6] = fill;
     __syncthreads();
+    // the workgroup's histogram goes to the global one (contiguous atomics) and, as a dense
+    // row, to blk_hist: T3's workgroup of the same index sorts exactly these entries and
+    // needs the per-tile counts again
+    uint32_t *row = blk_hist + (size_t)blockIdx.x * g.ntiles;
     for (int t = threadIdx.x; t < g.ntiles; t += kBlock) {
         uint32_t c = s_hist[t];
+        row[t] = c;
         if (c) atomicAdd(&tile_hist[t], c);
     }
 }
@@ -519,12 +525,12 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *__restrict__ tile_
 // store each).  Four entries per lane are in flight at a time: the loops are latency-bound.
 template <int WPR>  // waves per list region: the loops are latency chains, more waves shorten them
 __global__ __launch_bounds__(kBlock * WPR) void k_scatter(Lists L, int ntiles, int tshift,
+                                                          const uint32_t *__restrict__ blk_hist,
                                                           uint32_t *__restrict__ cursor, Entry *__restrict__ binned,
                                                           int dbg) {
     constexpr int T = kBlock * WPR;
-    extern __shared__ uint32_t s_cnt[];  // [ntiles] counts, then running write positions
-    for (int t = threadIdx.x; t < ntiles; t += T) s_cnt[t] = 0;
-    __syncthreads();
+    extern __shared__ uint32_t s_cnt[];  // running write positions per tile (after the claims)
+    const uint32_t *row = blk_hist + (size_t)blockIdx.x * ntiles;  // T1's counts for these entries
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint64_t region = (uint64_t)blockIdx.x * (kBlock / 64) + (w / WPR);
     const uint32_t first = (uint32_t)(w % WPR) * 64 + lane, step = 64 * WPR;
@@ -532,21 +538,13 @@ __global__ __launch_bounds__(kBlock * WPR) void k_scatter(Lists L, int ntiles, i
     const uint32_t *__restrict__ my_t = L.tiled + base, *__restrict__ my_d = L.depth + base,
                                  *__restrict__ my_i = L.idx + base;
     uint32_t cnt = L.counts[region];
-    if (dbg & 1) cnt = 0;
-    for (uint32_t e = first; e < cnt; e += 4 * step) {
-        uint32_t t[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) t[k] = (e + step * k < cnt) ? my_t[e + step * k] : 0xFFFFFFFFu;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) lds_hist_add(s_cnt, t[k] >> tshift, t[k] != 0xFFFFFFFFu);
-    }
-    __syncthreads();
+    if (dbg & 2) cnt = 0;
     // claim this workgroup's run in every tile it touches; the returning atomics of four
     // tiles are in flight together (their ~microsecond round trips would otherwise serialise)
     for (int t0 = threadIdx.x; t0 < ntiles; t0 += 4 * T) {
         uint32_t c[4], r[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) c[k] = (t0 + k * T < ntiles) ? s_cnt[t0 + k * T] : 0u;
+        for (int k = 0; k < 4; ++k) c[k] = (t0 + k * T < ntiles) ? row[t0 + k * T] : 0u;
 #pragma unroll
         for (int k = 0; k < 4; ++k) r[k] = c[k] ? atomicAdd(&cursor[t0 + k * T], c[k]) : 0u;
 #pragma unroll
@@ -554,7 +552,6 @@ __global__ __launch_bounds__(kBlock * WPR) void k_scatter(Lists L, int ntiles, i
             if (t0 + k * T < ntiles) s_cnt[t0 + k * T] = r[k];
     }
     __syncthreads();
-    if (dbg & 2) cnt = 0;
     for (uint32_t e = first; e < cnt; e += 4 * step) {
         uint32_t t[4], d[4], ix[4];
 #pragma unroll
@@ -573,6 +570,85 @@ __global__ __launch_bounds__(kBlock * WPR) void k_scatter(Lists L, int ntiles, i
     }
 }
 
+__device__ __forceinline__ float min2(float a, float b) { return a < b ? a : b; }  // project_cloud.cu:46-49
+
+// F1 folded into T4: the finished depth tile is still in LDS, so the four min-pool levels
+// (A8, project_cloud.cu:28-53) of the tile and its min / max partial (A12, render.cu:168-240)
+// are produced here instead of by k_pyramid re-reading the depth buffer.  Same rules as
+// k_pyramid: level i pixel (x, y) exists iff x < w[i], y < h[i]; min / max over the depth BIT
+// patterns of rows < n_eff_rows, sentinel skipped.  `scr` = 4 * tpix free LDS words.
+__device__ __forceinline__ void tile_pyramid(const uint32_t *s_depth, uint32_t *scr, const TileGeom &g, int tx0, int ty0,
+                                             const FilterLevels &L, uint32_t n_eff_rows, uint32_t *part_min,
+                                             uint32_t *part_max, int tile, int tid, int nthreads) {
+    const int tw = 1 << g.tw_shift, w1 = tw >> 1, n1 = w1 * 16, sh1 = g.tw_shift - 1;  // widths are powers of two
+    float *s1 = reinterpret_cast<float *>(scr), *s2 = s1 + n1, *s3 = s2 + (n1 >> 2);
+    uint32_t *s_mm = scr + n1 + (n1 >> 2) + (n1 >> 4);  // [2 * waves]
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (int q = tid; q < n1; q += nthreads) {
+        const int lx = q & (w1 - 1), ly = q >> sh1, gx = (tx0 >> 1) + lx, gy = (ty0 >> 1) + ly;
+        const uint32_t *c = s_depth + (2 * ly) * tw + 2 * lx;
+        const uint32_t b[4] = {c[0], c[1], c[tw], c[tw + 1]};
+        float v = min2(min2(__uint_as_float(b[0]), __uint_as_float(b[1])), min2(__uint_as_float(b[2]), __uint_as_float(b[3])));
+        if (gx < L.w[1] && gy < L.h[1]) {
+            L.lv[1][(size_t)gy * L.w[1] + gx] = v;
+            if ((uint32_t)(2 * gy) < n_eff_rows) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (b[k] != RTR_EMPTY) {
+                        lo = b[k] < lo ? b[k] : lo;
+                        hi = b[k] > hi ? b[k] : hi;
+                    }
+            }
+        }
+        s1[q] = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t ol = __shfl_xor(lo, off, 64), oh = __shfl_xor(hi, off, 64);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    const int nw = nthreads >> 6;
+    if ((tid & 63) == 0) {
+        s_mm[tid >> 6] = lo;
+        s_mm[nw + (tid >> 6)] = hi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t a = s_mm[0], b = s_mm[nw];
+        for (int k = 1; k < nw; ++k) {
+            a = s_mm[k] < a ? s_mm[k] : a;
+            b = s_mm[nw + k] > b ? s_mm[nw + k] : b;
+        }
+        part_min[tile] = a;
+        part_max[tile] = b;
+    }
+    const int w2 = w1 >> 1, n2 = n1 >> 2;
+    for (int q = tid; q < n2; q += nthreads) {
+        const int lx = q & (w2 - 1), ly = q >> (sh1 - 1), gx = (tx0 >> 2) + lx, gy = (ty0 >> 2) + ly;
+        const float *c = s1 + (2 * ly) * w1 + 2 * lx;
+        float v = min2(min2(c[0], c[1]), min2(c[w1], c[w1 + 1]));
+        if (gx < L.w[2] && gy < L.h[2]) L.lv[2][(size_t)gy * L.w[2] + gx] = v;
+        s2[q] = v;
+    }
+    __syncthreads();
+    const int w3 = w2 >> 1, n3 = n2 >> 2;
+    for (int q = tid; q < n3; q += nthreads) {
+        const int lx = q & (w3 - 1), ly = q >> (sh1 - 2), gx = (tx0 >> 3) + lx, gy = (ty0 >> 3) + ly;
+        const float *c = s2 + (2 * ly) * w2 + 2 * lx;
+        float v = min2(min2(c[0], c[1]), min2(c[w2], c[w2 + 1]));
+        if (gx < L.w[3] && gy < L.h[3]) L.lv[3][(size_t)gy * L.w[3] + gx] = v;
+        s3[q] = v;
+    }
+    __syncthreads();
+    const int w4 = w3 >> 1, n4 = n3 >> 2;
+    for (int q = tid; q < n4; q += nthreads) {
+        const int lx = q & (w4 - 1), ly = q >> (sh1 - 3), gx = (tx0 >> 4) + lx, gy = (ty0 >> 4) + ly;
+        const float *c = s3 + (2 * ly) * w3 + 2 * lx;
+        if (gx < L.w[4] && gy < L.h[4]) L.lv[4][(size_t)gy * L.w[4] + gx] = min2(min2(c[0], c[1]), min2(c[w3], c[w3 + 1]));
+    }
+}
+
 // T4: per-tile LDS z-buffer.  MODE 0 = whole frame (min + accumulate + resolve, writes
 // depth / image / optionally the accumulators); MODE 1 = min only (depth = min(depth,
 // tile min): the phase call before the multi-GPU MIN all-reduce); MODE 2 = accumulate
@@ -585,7 +661,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__
                                                         const uint32_t *__restrict__ rgba, TileGeom g, int W, int H,
                                                         float window, uint32_t *__restrict__ depth,
                                                         uint32_t *__restrict__ acc, uint8_t *__restrict__ img,
-                                                        int write_acc) {
+                                                        int write_acc, TilePyr pyr) {
     extern __shared__ uint32_t s_mem[];
     const int tpix = 32 << g.tw_shift;  // pixels per tile
     uint32_t *s_depth = s_mem;          // [tpix]
@@ -656,7 +732,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__
         __syncthreads();
     }
     // write-out: rows of the tile are contiguous in memory
-    if (dbg & 16) return;
+    if ((dbg & 16) && !pyr.enable) return;
     for (int p = tid; p < tpix; p += T) {
         int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
         bool inb = x < W && y < H;
@@ -702,22 +778,24 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__
                 if (x < W && y < H) img[((size_t)y * W + x) * 3 + ch] = s_rgb[q];
             }
         }
+        if (pyr.enable)  // s_acc is free now (the colours were resolved into s_rgb before the barrier)
+            tile_pyramid(s_depth, s_acc, g, tx0, ty0, pyr.L, pyr.n_eff_rows, pyr.part_min, pyr.part_max, tile, tid, T);
     }
 }
 
 void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const Lists &L,
-                        uint32_t *tile_hist, const float *bounds) {
+                        uint32_t *tile_hist, uint32_t *blk_hist, const float *bounds) {
     TileGeom g = tile_geom(W, H);
     uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) return;
     if (bounds)
         hipLaunchKernelGGL(k_project_bin<true>, dim3(point_grid(n4)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s,
                            (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, g, L, tile_hist,
-                           bounds);
+                           blk_hist, bounds);
     else
         hipLaunchKernelGGL(k_project_bin<false>, dim3(point_grid(n4)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s,
                            (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, g, L, tile_hist,
-                           bounds);
+                           blk_hist, bounds);
 }
 
 // bounding box of every 256-point chunk (the unit one wave of T1 handles per iteration):
@@ -770,23 +848,26 @@ void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const Lists &L
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, B.tile_hist, B.tile_start, B.cursor, g.ntiles);
     if (n4 == 0) return;
     hipLaunchKernelGGL(k_scatter<kScatterWPR>, dim3(point_grid(n4)), dim3(kBlock * kScatterWPR),
-                       g.ntiles * sizeof(uint32_t), s, L, g.ntiles, g.tw_shift + 5, B.cursor, B.entries, g_debug_skip & 3);
+                       g.ntiles * sizeof(uint32_t), s, L, g.ntiles, g.tw_shift + 5, B.blk_hist, B.cursor, B.entries,
+                       g_debug_skip & 3);
 }
 
 void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const Bins &B, float window, uint32_t *depth,
-                 uint32_t *acc, uint8_t *img, int write_acc) {
+                 uint32_t *acc, uint8_t *img, int write_acc, const TilePyr *pyr) {
     TileGeom g = tile_geom(W, H);
     size_t tpix = (size_t)32 << g.tw_shift;
     size_t lds = (mode == 1 ? tpix : 5 * tpix) * sizeof(uint32_t) + (mode == 0 ? 3 * tpix : 0);
+    TilePyr none{};
+    none.enable = 0;
     if (mode == 0)
-        hipLaunchKernelGGL(k_tile<0>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start,
-                           c.rgba, g, W, H, window, depth, acc, img, write_acc | ((g_debug_skip >> 2) << 10));
+        hipLaunchKernelGGL(k_tile<0>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, c.rgba, g, W,
+                           H, window, depth, acc, img, write_acc | ((g_debug_skip >> 2) << 10), pyr ? *pyr : none);
     else if (mode == 1)
-        hipLaunchKernelGGL(k_tile<1>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start,
-                           c.rgba, g, W, H, window, depth, acc, img, 0);
+        hipLaunchKernelGGL(k_tile<1>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, c.rgba, g, W,
+                           H, window, depth, acc, img, 0, none);
     else
-        hipLaunchKernelGGL(k_tile<2>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start,
-                           c.rgba, g, W, H, window, depth, acc, img, 1);
+        hipLaunchKernelGGL(k_tile<2>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, c.rgba, g, W,
+                           H, window, depth, acc, img, 1, none);
 }
 
 // ---------------------------------------------------------------------------------
@@ -833,8 +914,6 @@ void launch_resolve(hipStream_t s, const uint32_t *acc, uint8_t *img, size_t npi
 //                  (A10) and in-place bilinear fill of rejected pixels (A11)
 //   F5 k_final   : level-0 compare + removeMask + fp16 tensor (A13), four pixels a thread
 // Arithmetic is op-for-op that of oracle/rtr_oracle.c.
-
-__device__ __forceinline__ float min2(float a, float b) { return a < b ? a : b; }  // project_cloud.cu:46-49
 
 // F1.  A8 reduce (project_cloud.cu:28-53) for every level at once.  Level i pixel (x, y)
 // exists iff x < w[i], y < h[i] (dims halve with integer division), and then all four
@@ -1096,14 +1175,19 @@ __global__ __launch_bounds__(kBlock) void k_final(const float *__restrict__ l1, 
 // A14 applyDepthFilter (project_cloud.cu:331-392)
 void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, uint8_t *img, uint8_t *mask,
                    uint16_t *tensor, uint32_t *minmax, uint32_t *part_min, uint32_t *part_max, int W, int H,
-                   float strength, float thr) {
+                   float strength, float thr, int pyramid_parts) {
     auto blocks = [](size_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); };
     const int nl = L.levels;
     const int h_eff = (H >> nl) << nl;
-    const int tiles_x = (W + 31) / 32, tiles_y = (H + 31) / 32, nparts = tiles_x * tiles_y;
-    FilterLevels L4 = L;
-    if (L4.levels > 4) L4.levels = 4;
-    hipLaunchKernelGGL(k_pyramid, dim3(nparts), dim3(kBlock), 0, s, L4, tiles_x, (uint32_t)h_eff, part_min, part_max);
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + 31) / 32;
+    int nparts = tiles_x * tiles_y;
+    if (pyramid_parts > 0) {  // T4 already produced levels 1..4 and the per-tile partials
+        nparts = pyramid_parts;
+    } else {
+        FilterLevels L4 = L;
+        if (L4.levels > 4) L4.levels = 4;
+        hipLaunchKernelGGL(k_pyramid, dim3(nparts), dim3(kBlock), 0, s, L4, tiles_x, (uint32_t)h_eff, part_min, part_max);
+    }
     for (int i = 5; i <= nl; ++i)
         hipLaunchKernelGGL(k_reduce, blocks((size_t)L.w[i] * L.h[i]), dim3(kBlock), 0, s, L.lv[i - 1], L.lv[i], L.w[i],
                            L.h[i]);
