@@ -102,7 +102,7 @@ void free_frame(rtr_ctx *c) {
     c->list_valid = false;
     dfree(c->depth); dfree(c->acc); dfree(c->img); dfree(c->mask); dfree(c->part_min); dfree(c->part_max); dfree(c->tensor);
     for (int i = 1; i <= 8; ++i) dfree(c->lv.lv[i]);
-    dfree(c->bins.tile_hist); dfree(c->bins.tile_start); dfree(c->bins.cursor); dfree(c->bins.blk_hist);
+    dfree(c->bins.tile_hist); dfree(c->bins.tile_start); dfree(c->bins.cursor); dfree(c->bins.order); dfree(c->bins.blk_hist);
     c->tiles_n = 0; c->blk_hist_n = 0;
     c->lv.lv[0] = nullptr;
     c->W = c->H = 0;
@@ -124,10 +124,11 @@ void free_cloud(rtr_ctx *c) {
 int ensure_tiles(rtr_ctx *c) {
     int nt = rtr::tile_count(c->W, c->H);
     if (c->bins.tile_hist && c->tiles_n == nt) return RTR_OK;
-    dfree(c->bins.tile_hist); dfree(c->bins.tile_start); dfree(c->bins.cursor);
+    dfree(c->bins.tile_hist); dfree(c->bins.tile_start); dfree(c->bins.cursor); dfree(c->bins.order);
     HIP_TRY(c, hipMalloc((void **)&c->bins.tile_hist, (size_t)nt * 4));
     HIP_TRY(c, hipMalloc((void **)&c->bins.tile_start, (size_t)(nt + 1) * 4));
     HIP_TRY(c, hipMalloc((void **)&c->bins.cursor, (size_t)nt * 4));
+    HIP_TRY(c, hipMalloc((void **)&c->bins.order, (size_t)nt * 4));
     HIP_TRY(c, hipMemsetAsync(c->bins.tile_hist, 0, (size_t)nt * 4, c->stream));
     c->tiles_n = nt;
     return RTR_OK;

@@ -43,6 +43,7 @@ struct Entry {  // 12 bytes, moved with one dwordx3 store
 struct Bins {
     Entry *entries;                             // entries counting-sorted by tile
     uint32_t *tile_hist, *tile_start, *cursor;  // [ntiles], [ntiles + 1], [ntiles]
+    uint32_t *order;                            // [ntiles]: tile launch order of T4, heavy tiles first
     uint32_t *blk_hist;                         // [point-grid workgroups][ntiles]: T1's per-workgroup counts
 };
 

@@ -492,31 +492,54 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
 // T2: exclusive scan of the histogram -> tile_start[0..ntiles], cursor[] = start, and the
 // histogram is re-zeroed for the next frame.  One workgroup of 1024 threads.
 __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *__restrict__ tile_hist, uint32_t *__restrict__ tile_start,
-                                                    uint32_t *__restrict__ cursor, int ntiles) {
+                                                    uint32_t *__restrict__ cursor, uint32_t *__restrict__ order,
+                                                    int ntiles) {
     __shared__ uint32_t s_part[1024];
-    const int per = (ntiles + 1023) / 1024;
+    const int per = (ntiles + 1023) / 1024;  // <= 4 (ntiles <= 4096)
     const int lo = threadIdx.x * per;
-    uint32_t sum = 0;
-    for (int k = 0; k < per; ++k)
-        if (lo + k < ntiles) sum += tile_hist[lo + k];
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-        uint32_t v = (threadIdx.x >= (unsigned)off) ? s_part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = s_part[threadIdx.x] - sum;  // exclusive prefix of this thread's chunk
-    for (int k = 0; k < per; ++k)
+    uint32_t cnt[4] = {0, 0, 0, 0}, sum = 0;
+    for (int k = 0; k < per && k < 4; ++k)
         if (lo + k < ntiles) {
-            uint32_t c = tile_hist[lo + k];
+            cnt[k] = tile_hist[lo + k];
+            sum += cnt[k];
+        }
+    auto scan = [&](uint32_t mine) {  // Hillis-Steele inclusive scan over the workgroup
+        s_part[threadIdx.x] = mine;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            uint32_t v = (threadIdx.x >= (unsigned)off) ? s_part[threadIdx.x - off] : 0u;
+            __syncthreads();
+            s_part[threadIdx.x] += v;
+            __syncthreads();
+        }
+    };
+    scan(sum);
+    const uint32_t total = s_part[1023];
+    uint32_t run = s_part[threadIdx.x] - sum;  // exclusive prefix of this thread's chunk
+    for (int k = 0; k < per && k < 4; ++k)
+        if (lo + k < ntiles) {
             tile_start[lo + k] = run;
             cursor[lo + k] = run;
             tile_hist[lo + k] = 0;
-            run += c;
+            run += cnt[k];
         }
-    if (threadIdx.x == 1023) tile_start[ntiles] = s_part[1023];
+    if (threadIdx.x == 1023) tile_start[ntiles] = total;
+    __syncthreads();
+    // launch order of the tile kernel: tiles with more than twice the mean entry count first,
+    // so the few heavy tiles that bound T4 start at once instead of trailing the launch
+    const uint32_t thr = 2u * (total / (uint32_t)ntiles) + 1u;
+    uint32_t heavy = 0;
+    for (int k = 0; k < per && k < 4; ++k) heavy += (lo + k < ntiles && cnt[k] > thr) ? 1u : 0u;
+    scan(heavy);
+    const uint32_t n_heavy = s_part[1023];
+    uint32_t h_before = s_part[threadIdx.x] - heavy;
+    for (int k = 0; k < per && k < 4; ++k)
+        if (lo + k < ntiles) {
+            const bool h = cnt[k] > thr;
+            const uint32_t pos = h ? h_before : n_heavy + (uint32_t)(lo + k) - h_before;
+            order[pos] = (uint32_t)(lo + k);
+            h_before += h ? 1u : 0u;
+        }
 }
 
 // T3: counting sort by tile.  Workgroup b re-reads the four wave lists that workgroup b of
@@ -658,6 +681,7 @@ __device__ __forceinline__ void tile_pyramid(const uint32_t *s_depth, uint32_t *
 template <int MODE>
 __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__ binned,
                                                         const uint32_t *__restrict__ tile_start,
+                                                        const uint32_t *__restrict__ order,
                                                         const uint32_t *__restrict__ rgba, TileGeom g, int W, int H,
                                                         float window, uint32_t *__restrict__ depth,
                                                         uint32_t *__restrict__ acc, uint8_t *__restrict__ img,
@@ -667,7 +691,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__
     uint32_t *s_depth = s_mem;          // [tpix]
     uint32_t *s_acc = s_mem + tpix;     // [4 * tpix]
     uint8_t *s_rgb = reinterpret_cast<uint8_t *>(s_mem + 5 * tpix);  // [3 * tpix] (MODE 0)
-    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int tile = (int)order[blockIdx.x], tid = threadIdx.x;  // heavy tiles first (k_tile_scan)
     const int tx0 = (tile % g.tiles_x) << g.tw_shift, ty0 = (tile / g.tiles_x) * kTileH;
     const int tw = 1 << g.tw_shift, tmask = tpix - 1;
     const uint32_t e0 = tile_start[tile];
@@ -845,7 +869,7 @@ void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds) {
 void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const Lists &L, const Bins &B) {
     TileGeom g = tile_geom(W, H);
     uint64_t n4 = (c.n + 3) / 4;
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, B.tile_hist, B.tile_start, B.cursor, g.ntiles);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, B.tile_hist, B.tile_start, B.cursor, B.order, g.ntiles);
     if (n4 == 0) return;
     hipLaunchKernelGGL(k_scatter<kScatterWPR>, dim3(point_grid(n4)), dim3(kBlock * kScatterWPR),
                        g.ntiles * sizeof(uint32_t), s, L, g.ntiles, g.tw_shift + 5, B.blk_hist, B.cursor, B.entries,
@@ -860,13 +884,16 @@ void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const Bi
     TilePyr none{};
     none.enable = 0;
     if (mode == 0)
-        hipLaunchKernelGGL(k_tile<0>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, c.rgba, g, W,
+        hipLaunchKernelGGL(k_tile<0>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, B.order, c.rgba, g,
+                           W,
                            H, window, depth, acc, img, write_acc | ((g_debug_skip >> 2) << 10), pyr ? *pyr : none);
     else if (mode == 1)
-        hipLaunchKernelGGL(k_tile<1>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, c.rgba, g, W,
+        hipLaunchKernelGGL(k_tile<1>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, B.order, c.rgba, g,
+                           W,
                            H, window, depth, acc, img, 0, none);
     else
-        hipLaunchKernelGGL(k_tile<2>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, c.rgba, g, W,
+        hipLaunchKernelGGL(k_tile<2>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, B.order, c.rgba, g,
+                           W,
                            H, window, depth, acc, img, 1, none);
 }
 
