@@ -295,7 +295,6 @@ void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, in
 //                      the resolve of one tile in one launch.
 // Results are identical to the atomic form because min and integer sums commute.
 constexpr int kTileH = 32;
-constexpr int kRing = 128;  // entries of a wave's LDS staging ring in k_project_bin (power of two)
 constexpr int kTileThreads = 512;
 constexpr int kTileBatch = 8;   // entries in flight per thread in k_tile
 constexpr int kScatterWPR = 2;  // k_scatter waves per list region
@@ -363,14 +362,9 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
                                                         int H, TileGeom g, Lists L, uint32_t *__restrict__ tile_hist,
                                                         uint32_t *__restrict__ blk_hist,
                                                         const float *__restrict__ bounds) {
-    extern __shared__ uint32_t s_hist[];  // [ntiles] tile histogram, then one 128-entry ring per wave
+    extern __shared__ uint32_t s_hist[];
     for (int t = threadIdx.x; t < g.ntiles; t += kBlock) s_hist[t] = 0;
     __syncthreads();
-    // List entries are staged in a per-wave LDS ring and leave in whole 64-entry groups, so
-    // every list store is a full-wave coalesced 256 B write even when only a few lanes of an
-    // iteration are inside the frustum (incoherent point order).  The ring is private to the
-    // wave: no barriers, LDS ops of one wave execute in order.
-    uint32_t *ring = s_hist + g.ntiles + (threadIdx.x >> 6) * (3 * kRing);
     const float fW = (float)W, fH = (float)H;
     const float hiW = f_add(fW, 0.25f), hiH = f_add(fH, 0.25f);
     const uint64_t gtid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -379,14 +373,11 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
     const int tshift = g.tw_shift + 5, twm = (1 << g.tw_shift) - 1;
     const uint64_t base = (gtid >> 6) * L.region_cap;
     uint32_t *__restrict__ my_t = L.tiled + base, *__restrict__ my_d = L.depth + base, *__restrict__ my_i = L.idx + base;
-    uint32_t fill = 0, flushed = 0;  // entries appended to the ring / already written to the list
+    uint32_t fill = 0;
 
-    // one quad (four points per lane) of the wave.  ALL 64 lanes run it (the ring flush is a
-    // full-wave store); lanes past the end of the cloud re-read the wave's first quad and are
-    // masked by `live`.  Every exit is wave-uniform.
-    auto do_quad = [&](uint64_t i, bool live) {
-        const uint64_t ii = live ? i : i - (uint64_t)lane;
-        float4 X = ld_stream(x4 + ii), Y = ld_stream(y4 + ii), Z = ld_stream(z4 + ii);
+    // one quad (four points per lane) of the wave; every exit is wave-uniform
+    auto do_quad = [&](uint64_t i) {
+        float4 X = ld_stream(x4 + i), Y = ld_stream(y4 + i), Z = ld_stream(z4 + i);
         const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
         float rz[4];
         bool front = false;
@@ -395,7 +386,6 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
             rz[k] = f_add(fmaf(P.m[10], zs[k], fmaf(P.m[9], ys[k], f_mul(P.m[8], xs[k]))), P.m[11]);
             front = front || (rz[k] > 0.0f);  // render.cu:63 (NaN fails)
         }
-        front = front && live;
         if (__ballot(front) == 0ull) return;
         float rx[4], ry[4];
         bool maybe[4], any = false;
@@ -405,7 +395,7 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
             ry[k] = f_add(fmaf(P.m[6], zs[k], fmaf(P.m[5], ys[k], f_mul(P.m[4], xs[k]))), P.m[7]);
             const float z = rz[k], lo = f_mul(-0.75f, z);
             const bool out = (z > 1e-30f) && ((rx[k] < lo) || (rx[k] > f_mul(hiW, z)) || (ry[k] < lo) || (ry[k] > f_mul(hiH, z)));
-            maybe[k] = live && (z > 0.0f) && !out;
+            maybe[k] = (z > 0.0f) && !out;
             any = any || maybe[k];
         }
         if (__ballot(any) == 0ull) return;
@@ -423,28 +413,19 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
                 int u = (int)fu, v = (int)fv;
                 uint32_t tile = (uint32_t)((v >> 5) * g.tiles_x + (u >> g.tw_shift));
                 uint32_t tiled = (tile << tshift) | (uint32_t)(((v & 31) << g.tw_shift) | (u & twm));
-                uint32_t pos = (fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & (kRing - 1);
-                ring[pos] = tiled;
-                ring[kRing + pos] = __float_as_uint(rz[k]);
-                ring[2 * kRing + pos] = (uint32_t)(4 * i + k);
+                uint32_t pos = fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                my_t[pos] = tiled;
+                my_d[pos] = __float_as_uint(rz[k]);
+                my_i[pos] = (uint32_t)(4 * i + k);
                 lds_hist_add(s_hist, tile, true);  // exec = the in-frustum lanes
             }
             fill += (uint32_t)__popcll(m);
-            if (fill - flushed >= 64u) {  // wave-uniform: at most 63 were pending, at most 64 came in
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const uint32_t src = (flushed + lane) & (kRing - 1);
-                my_t[flushed + lane] = ring[src];
-                my_d[flushed + lane] = ring[kRing + src];
-                my_i[flushed + lane] = ring[2 * kRing + src];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                flushed += 64u;
-            }
         }
     };
 
     if (!CULL) {
-        for (uint64_t i = gtid; i - (uint64_t)lane < n4; i += stride) do_quad(i, i < n4);  // wave-uniform trip count
+        for (uint64_t i = gtid; i < n4; i += stride) do_quad(i);
     } else {
         // The wave owns chunks wave, wave + NW, wave + 2 NW, ... (the same grid-stride order as
         // above).  64 of them are tested at once, one per lane, then only the survivors are
@@ -491,16 +472,9 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
                 const int l = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
                 const uint64_t i = (wave + (g0 + l) * NW) * 64 + lane;
-                do_quad(i, i < n4);
+                if (i < n4) do_quad(i);
             }
         }
-    }
-    if ((uint32_t)lane < fill - flushed) {  // the ring's remainder (< 64 entries)
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const uint32_t src = (flushed + lane) & (kRing - 1);
-        my_t[flushed + lane] = ring[src];
-        my_d[flushed + lane] = ring[kRing + src];
-        my_i[flushed + lane] = ring[2 * kRing + src];
     }
     if (lane == 0) L.counts[gtid >> 6] = fill;
     __syncthreads();
@@ -839,13 +813,11 @@ void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int
     uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) return;
     if (bounds)
-        hipLaunchKernelGGL(k_project_bin<true>, dim3(point_grid(n4)), dim3(kBlock),
-                           (g.ntiles + (kBlock / 64) * 3 * kRing) * sizeof(uint32_t), s,
+        hipLaunchKernelGGL(k_project_bin<true>, dim3(point_grid(n4)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s,
                            (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, g, L, tile_hist,
                            blk_hist, bounds);
     else
-        hipLaunchKernelGGL(k_project_bin<false>, dim3(point_grid(n4)), dim3(kBlock),
-                           (g.ntiles + (kBlock / 64) * 3 * kRing) * sizeof(uint32_t), s,
+        hipLaunchKernelGGL(k_project_bin<false>, dim3(point_grid(n4)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s,
                            (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, g, L, tile_hist,
                            blk_hist, bounds);
 }
