@@ -257,8 +257,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "C3: %d-point synthetic %s cloud -> %dx%d, 1x1 splat z-buffer%s"
-                                   % (total, args.scene, W, H, " + depth-heuristic prefilter" if with_filter else ""),
+            "config": {"workload": "%s: %d-point synthetic %s cloud -> %dx%d, 1x1 splat z-buffer%s"
+                                   % (("C3" if (args.points, W, H) == (100_000_000, 1920, 1080) and with_filter else "custom"),
+                                      total, args.scene, W, H, " + depth-heuristic prefilter" if with_filter else ""),
                        "points_total": total, "points_per_gpu": n_local, "scene": args.scene,
                        "resolution": [W, H], "prefilter": with_filter,
                        "parallelism": ("point-shard x%d, RCCL all-reduce MIN(depth) + %s SUM(accum), %d frames in "
