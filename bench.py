@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--force-exchange", action="store_true",
                     help="rehearsal on ONE GPU: run the N>1 code path (streams, RCCL collectives in a 1-rank "
                          "group, 2 frames in flight); the numbers are not a benchmark result")
+    ap.add_argument("--time-all-kernels", action="store_true",
+                    help="bracket every phase with HIP events (default: only the dominant streaming kernel, two "
+                         "event records per frame; the full per-kernel table is in profiles/)")
     ap.add_argument("--no-extra", action="store_true", help="skip the separately reported chunk-culling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=10_000_000)
@@ -192,7 +195,7 @@ def main():
         render(renderers, k, poses[k])
     sync()
     for pj in projs:
-        pj.timing_enable(True)
+        pj.timing_enable(1 if args.time_all_kernels else 2)
         pj.timing_reset()
     t0 = time.perf_counter()
     for k in range(args.steps):

@@ -161,8 +161,9 @@ typedef enum {
 /* Read-only probe: same loads and projection arithmetic as the point passes, no frame-
  * buffer traffic -- measures the streaming ceiling of the access pattern. */
 int rtr_stream_probe(rtr_ctx *ctx, const float P[16]);
-/* When enabled, every phase is bracketed by hipEvents on the context's stream;
- * rtr_timing_get synchronises and returns the accumulated device time. */
+/* on = 1: every phase is bracketed by hipEvents on the context's stream; on = 2: only the
+ * streaming point kernels (RTR_K_MIN_DEPTH, RTR_K_ACCUMULATE), i.e. two event records per
+ * frame; 0: off.  rtr_timing_get synchronises and returns the accumulated device time. */
 int rtr_timing_enable(rtr_ctx *ctx, int on);
 int rtr_timing_reset(rtr_ctx *ctx);
 int rtr_timing_get(rtr_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);

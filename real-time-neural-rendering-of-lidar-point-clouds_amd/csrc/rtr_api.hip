@@ -55,7 +55,7 @@ struct rtr_ctx {
     int opt_cull = 0;           // per-chunk frustum culling in T1
 
     // timing
-    bool timing = false;
+    int timing = 0;  // 0 off, 1 every phase, 2 only the streaming kernel (RTR_K_MIN_DEPTH / ACCUMULATE)
     struct Span { hipEvent_t a, b; int k; };
     std::vector<Span> pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
@@ -181,6 +181,7 @@ struct Timed {  // brackets one phase with hipEvents on the context's stream
     rtr_ctx *c; int k; hipEvent_t a = nullptr, b = nullptr;
     Timed(rtr_ctx *c_, int k_) : c(c_), k(k_) {
         if (!c->timing) return;
+        if (c->timing == 2 && k != RTR_K_MIN_DEPTH && k != RTR_K_ACCUMULATE) return;
         if (c->pool.empty()) {
             (void)hipEventCreate(&a); (void)hipEventCreate(&b);
         } else {
@@ -741,7 +742,7 @@ int rtr_timing_enable(rtr_ctx *c, int on) {
     if (!c) return RTR_ERR_INVALID;
     DevGuard g(c->device);
     (void)collect_timing(c);
-    c->timing = on != 0;
+    c->timing = on < 0 ? 0 : (on > 2 ? 1 : on);
     return RTR_OK;
 }
 

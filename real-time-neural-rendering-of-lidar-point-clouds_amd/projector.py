@@ -184,7 +184,8 @@ class Projector:
 
     # -- measurement
     def timing_enable(self, on=True):
-        self._chk(self._lib.rtr_timing_enable(self._ctx, 1 if on else 0))
+        """True / 1: every phase, 2: only the streaming point kernels, False / 0: off."""
+        self._chk(self._lib.rtr_timing_enable(self._ctx, int(on)))
 
     def timing_reset(self):
         self._chk(self._lib.rtr_timing_reset(self._ctx))
