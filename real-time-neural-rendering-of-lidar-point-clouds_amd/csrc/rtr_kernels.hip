@@ -708,8 +708,17 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__
             s_depth[p] = RTR_EMPTY;
         }
     }
+    // Accumulators: the exact layout is two 64-bit words per pixel, (c0 | c1 << 32) and
+    // (c2 | count << 32).  LDS atomics are what bounds this kernel (about one lane per clock
+    // and CU), so tiles with <= 60000 entries first try ONE packed word per pixel and entry,
+    // c0 | c1 << 16 | c2 << 32 | count << 48: no 16-bit field can overflow while a pixel's
+    // count is <= 257 (255 * 257 = 65535), a carry can only move upwards inside the pixel's
+    // own word (so the count field never reads low), and the count cannot wrap below 65536
+    // entries.  If any pixel ends with count > 257 the whole tile is redone with the wide layout.
+    unsigned long long *s_acc64 = reinterpret_cast<unsigned long long *>(s_acc);
+    bool narrow = (MODE != 1) && (e1 - e0 <= 60000u);
     if (MODE != 1)
-        for (int p = tid; p < 4 * tpix; p += T) s_acc[p] = 0;
+        for (int p = tid; p < (narrow ? 2 : 4) * tpix; p += T) s_acc[p] = 0;
     __syncthreads();
     if (MODE != 2 && !(dbg & 4)) {
         for (uint32_t e = e0 + tid; e < e1; e += kTileBatch * T) {
@@ -726,7 +735,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__
         }
         __syncthreads();
     }
-    if (MODE != 1 && !(dbg & 8)) {
+    auto accumulate = [&](bool packed) {
         for (uint32_t e = e0 + tid; e < e1; e += kTileBatch * T) {
             uint32_t t[kTileBatch], d[kTileBatch], ix[kTileBatch];
 #pragma unroll
@@ -743,17 +752,35 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__
             for (int k = 0; k < kTileBatch; ++k) {
                 float m = __uint_as_float(s_depth[t[k] & tmask]);
                 hit[k] = !(__uint_as_float(d[k]) > f_add(m, window));  // render.cu:106
-                c[k] = hit[k] ? rgba[ix[k]] : 0u;
+                c[k] = hit[k] ? ((dbg & 32) ? ix[k] : rgba[ix[k]]) : 0u;  // dbg 32: timing experiment, no colour gather
             }
 #pragma unroll
             for (int k = 0; k < kTileBatch; ++k)
-                if (hit[k]) {  // render.cu:125-128 as two 64-bit LDS adds: (c0 | c1 << 32), (c2 | count << 32)
-                    unsigned long long *a = reinterpret_cast<unsigned long long *>(s_acc) + 2 * (t[k] & tmask);
-                    atomicAdd(a + 0, (unsigned long long)(c[k] & 0xFFu) | ((unsigned long long)((c[k] >> 8) & 0xFFu) << 32));
-                    atomicAdd(a + 1, (unsigned long long)((c[k] >> 16) & 0xFFu) | (1ull << 32));
+                if (hit[k]) {  // render.cu:125-128
+                    const unsigned long long c0 = c[k] & 0xFFu, c1 = (c[k] >> 8) & 0xFFu, c2 = (c[k] >> 16) & 0xFFu;
+                    if (packed) {
+                        atomicAdd(s_acc64 + (t[k] & tmask), c0 | (c1 << 16) | (c2 << 32) | (1ull << 48));
+                    } else {
+                        atomicAdd(s_acc64 + 2 * (t[k] & tmask) + 0, c0 | (c1 << 32));
+                        atomicAdd(s_acc64 + 2 * (t[k] & tmask) + 1, c2 | (1ull << 32));
+                    }
                 }
         }
+    };
+    if (MODE != 1 && !(dbg & 8)) {
+        accumulate(narrow);
         __syncthreads();
+        if (narrow) {
+            int over = 0;
+            for (int p = tid; p < tpix; p += T) over |= (s_acc64[p] >> 48) > 257ull;
+            if (__syncthreads_or(over)) {  // rare: some pixel blends more than 257 points
+                narrow = false;
+                for (int p = tid; p < 4 * tpix; p += T) s_acc[p] = 0;
+                __syncthreads();
+                accumulate(false);
+                __syncthreads();
+            }
+        }
     }
     // write-out: rows of the tile are contiguous in memory
     if ((dbg & 16) && !pyr.enable) return;
@@ -770,7 +797,16 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__
             }
         }
         if (MODE != 1) {
-            uint32_t a0 = s_acc[4 * p], a1 = s_acc[4 * p + 1], a2 = s_acc[4 * p + 2], c = s_acc[4 * p + 3];
+            uint32_t a0, a1, a2, c;
+            if (narrow) {
+                const unsigned long long pk = s_acc64[p];
+                a0 = (uint32_t)(pk & 0xFFFFu);
+                a1 = (uint32_t)((pk >> 16) & 0xFFFFu);
+                a2 = (uint32_t)((pk >> 32) & 0xFFFFu);
+                c = (uint32_t)(pk >> 48);
+            } else {
+                a0 = s_acc[4 * p], a1 = s_acc[4 * p + 1], a2 = s_acc[4 * p + 2], c = s_acc[4 * p + 3];
+            }
             if (MODE == 2) {
                 if (inb) {
                     uint4 o = reinterpret_cast<uint4 *>(acc)[gp];

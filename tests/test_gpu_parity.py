@@ -279,3 +279,16 @@ def test_culling_with_extreme_cameras(pkg, orc, projector):
             assert np.array_equal(img, ref["img"]), trial
     finally:
         projector.set_option("cull", 0)
+
+
+@pytest.mark.parametrize("n_same", [255, 256, 257, 258, 259, 600, 5000])
+def test_packed_accumulator_boundary(pkg, orc, projector, mode, n_same):
+    """The tile kernel's packed 16-bit accumulator fields hold exactly 257 points of value 255
+    (65535); one more must fall back to the wide layout.  All-255 colours are the worst case."""
+    P = kat_P(orc)
+    rng = np.random.default_rng(n_same)
+    pts = [(0.0, 0.0, 2.0)] * n_same + [(float(x), float(y), 2.0) for x, y in rng.uniform(-0.3, 0.3, size=(400, 2))]
+    cols = [(255, 255, 255)] * n_same + [tuple(int(v) for v in rng.integers(0, 256, 3)) for _ in range(400)]
+    xyzw, rgba = cloud(pts, cols)
+    ref = _check_frame(pkg, orc, projector, xyzw, rgba, P, 64, 48)
+    assert ref["acc"][24, 32, 3] >= n_same and tuple(ref["img"][24, 32]) != (0, 0, 0)
