@@ -53,6 +53,8 @@ struct rtr_ctx {
     int opt_keep_accum = 0;     // whole-frame calls also materialise RTR_BUF_ACCUM
     int opt_probe = 0;          // rtr_stream_probe variant (experiments)
     int opt_cull = 0;           // per-chunk frustum culling in T1
+    int opt_grid = rtr::kDefaultPointGrid;  // workgroups of the point kernels
+    int opt_debug = 0;          // timing experiments (frames become wrong)
 
     // timing
     int timing = 0;  // 0 off, 1 every phase, 2 only the streaming kernel (RTR_K_MIN_DEPTH / ACCUMULATE)
@@ -139,7 +141,7 @@ int ensure_tiles(rtr_ctx *c) {
 int ensure_lists(rtr_ctx *c) {
     if (c->lists.tiled && c->list_n == c->n) return RTR_OK;
     free_lists(c);
-    uint64_t waves = rtr::list_num_waves(c->n), cap = rtr::list_region_cap(c->n);
+    uint64_t waves = rtr::list_num_waves(c->n, c->opt_grid), cap = rtr::list_region_cap(c->n, c->opt_grid);
     c->lists.region_cap = cap;
     c->list_n = c->n;
     if (waves == 0) return RTR_OK;
@@ -175,7 +177,7 @@ rtr::Proj make_proj(const float P[16]) {
     return p;
 }
 
-rtr::Cloud cloud_of(const rtr_ctx *c) { return rtr::Cloud{c->x, c->y, c->z, c->rgba, c->n}; }
+rtr::Cloud cloud_of(const rtr_ctx *c) { return rtr::Cloud{c->x, c->y, c->z, c->rgba, c->n, c->opt_grid, c->opt_debug}; }
 
 struct Timed {  // brackets one phase with hipEvents on the context's stream
     rtr_ctx *c; int k; hipEvent_t a = nullptr, b = nullptr;
@@ -327,7 +329,7 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
         DevGuard g(c->device);
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         free_lists(c);
-        rtr::set_point_grid(value);
+        c->opt_grid = value;
         return RTR_OK;
     }
     if (!strcmp(key, "cull")) {
@@ -335,7 +337,7 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
         return RTR_OK;
     }
     if (!strcmp(key, "debug_skip")) {  // timing experiments only: the frame becomes wrong
-        rtr::set_debug_skip(value);
+        c->opt_debug = value;
         return RTR_OK;
     }
     if (!strcmp(key, "probe_variant")) {
@@ -396,19 +398,23 @@ int rtr_upload_points(rtr_ctx *c, const float *xyz, size_t xs, const uint8_t *rg
     NEED(c, n == 0 || (xyz && rgb), "xyz / rgb is NULL");
     NEED(c, xs >= 12 && xs % 4 == 0, "xyz_stride_bytes must be >= 12 and a multiple of 4");
     NEED(c, rs >= 3, "rgb_stride_bytes must be >= 3");
-    NEED(c, n < (1ull << 31) * 4ull, "too many points");
+    NEED(c, n < (1ull << 32), "too many points for one context (point indices are 32-bit): shard the cloud");
     DevGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     int rc = alloc_cloud(c, n);
     if (rc) return rc;
     // stage through device chunks; AoS -> SoA on the GPU
     const uint64_t chunk = 1ull << 24;
-    uint8_t *sx = nullptr, *sc = nullptr;
+    struct Staging {  // freed on every exit path
+        uint8_t *p = nullptr;
+        ~Staging() { if (p) (void)hipFree(p); }
+    } stx, stc;
     uint64_t m = n < chunk ? n : chunk;
     if (m) {
-        HIP_TRY(c, hipMalloc((void **)&sx, m * xs));
-        HIP_TRY(c, hipMalloc((void **)&sc, m * rs));
+        HIP_TRY(c, hipMalloc((void **)&stx.p, m * xs));
+        HIP_TRY(c, hipMalloc((void **)&stc.p, m * rs));
     }
+    uint8_t *sx = stx.p, *sc = stc.p;
     for (uint64_t off = 0; off < n; off += chunk) {
         uint64_t cnt = (n - off) < chunk ? (n - off) : chunk;
         HIP_TRY(c, hipMemcpyAsync(sx, (const uint8_t *)xyz + off * xs, cnt * xs, hipMemcpyHostToDevice, c->stream));
@@ -419,7 +425,6 @@ int rtr_upload_points(rtr_ctx *c, const float *xyz, size_t xs, const uint8_t *rg
     rtr::launch_pad_nan(c->stream, c->x, c->y, c->z, c->rgba, n, (n + 3) & ~3ull);
     rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    dfree(sx); dfree(sc);
     return launch_check(c, "aos_to_soa");
 }
 
@@ -428,6 +433,7 @@ int rtr_generate_synthetic(rtr_ctx *c, int scene, uint64_t seed, uint64_t first,
     NEED(c, scene == RTR_SCENE_UNIFORM_BOX || scene == RTR_SCENE_ROOM_SHELL, "unknown scene");
     NEED(c, first + count <= total, "first + count exceeds total");
     NEED(c, total < (1ull << 33), "total too large");
+    NEED(c, count < (1ull << 32), "too many points for one context (point indices are 32-bit): shard the cloud");
     DevGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     int rc = alloc_cloud(c, count);
@@ -536,13 +542,17 @@ int rtr_clear(rtr_ctx *c) {
     return launch_check(c, "clear");
 }
 
+// The binned form keeps one LDS counter per screen tile (<= 4096 tiles: up to 3840 x 2160);
+// larger frames fall back to the atomic form.
+static bool use_tiles(const rtr_ctx *c) { return c->opt_mode == 1 && rtr::tile_count(c->W, c->H) <= 4096; }
+
 // T1..T3 of the tile-binned form: stream + candidate lists + tile histogram, scan, scatter
 static int bin_points(rtr_ctx *c, const float P[16]) {
     c->list_valid = false;
     if (int rc = ensure_lists(c)) return rc;
     if (int rc = ensure_tiles(c)) return rc;
     {
-        size_t need = (size_t)(rtr::list_num_waves(c->n) / 4 + 1) * (size_t)c->tiles_n;
+        size_t need = (size_t)(rtr::list_num_waves(c->n, c->opt_grid) / 4 + 1) * (size_t)c->tiles_n;
         if (!c->bins.blk_hist || c->blk_hist_n != need) {
             dfree(c->bins.blk_hist);
             HIP_TRY(c, hipMalloc((void **)&c->bins.blk_hist, need * sizeof(uint32_t)));
@@ -569,7 +579,7 @@ int rtr_min_depth_pass(rtr_ctx *c, const float P[16]) {
     if (int rc = check_frame(c)) return rc;
     DevGuard g(c->device);
     c->list_valid = false;
-    if (c->opt_mode == 1) {
+    if (use_tiles(c)) {
         if (int rc = bin_points(c, P)) return rc;
         Timed t(c, RTR_K_TILE);
         rtr::launch_tile(c->stream, 1, cloud_of(c), c->W, c->H, c->bins, c->prm.depth_window, c->depth, c->acc, c->img,
@@ -588,7 +598,7 @@ int rtr_accumulate_pass(rtr_ctx *c, const float P[16]) {
     DevGuard g(c->device);
     // the bins are only usable for the matrix they were built with; otherwise re-project
     // the cloud like the reference does (render.cu:90-98)
-    const bool use_bins = c->opt_mode == 1 && c->list_valid && memcmp(c->list_P, P, sizeof c->list_P) == 0;
+    const bool use_bins = use_tiles(c) && c->list_valid && memcmp(c->list_P, P, sizeof c->list_P) == 0;
     if (use_bins) {
         Timed t(c, RTR_K_TILE);
         rtr::launch_tile(c->stream, 2, cloud_of(c), c->W, c->H, c->bins, c->prm.depth_window, c->depth, c->acc, c->img,
@@ -648,7 +658,7 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
         if (int rc = ensure_pyramid(c)) return rc;
     }
     int rc;
-    if (c->opt_mode == 1) {  // one launch does clear + min + accumulate + resolve per tile
+    if (use_tiles(c)) {  // one launch does clear + min + accumulate + resolve per tile
         DevGuard g(c->device);
         if ((rc = bin_points(c, P))) return rc;
         // with the default four levels the tile kernel also emits the prefilter's pyramid and

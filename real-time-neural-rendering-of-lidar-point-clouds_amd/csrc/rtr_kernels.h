@@ -17,6 +17,8 @@ struct Cloud {
     const float *x, *y, *z;  // SoA, padded to a multiple of 4 points with NaN
     const uint32_t *rgba;    // packed c0 | c1<<8 | c2<<16 | 255<<24
     uint64_t n;              // real point count
+    int grid;                // workgroups of the grid-stride point kernels (lists are sized for it)
+    int debug;               // timing experiments only: bit0/1 T3, bit2/3/4 T4 min/acc/write-out, bit5 no colour gather
 };
 
 struct FilterLevels {
@@ -54,10 +56,9 @@ void launch_accumulate(hipStream_t s, const Cloud &c, const Proj &P, int W, int 
                        uint32_t *acc, float window);
 // mode 1 (default): tile-binned pipeline -- T1 stream + lists + histogram, T2 scan + T3 scatter,
 // T4 per-tile LDS z-buffer (tile mode 0 whole frame, 1 min only, 2 accumulate only)
-void set_debug_skip(int bits);         // timing experiments: bit0/1 T3 count/move, bit2/3/4 T4 min/acc/write-out
-void set_point_grid(int blocks);       // grid of the point kernels (tuning; invalidates list sizes)
-uint64_t list_region_cap(uint64_t n);  // entries per wave region
-uint64_t list_num_waves(uint64_t n);   // number of wave regions
+constexpr int kDefaultPointGrid = 1024;
+uint64_t list_region_cap(uint64_t n, int grid);  // entries per wave region
+uint64_t list_num_waves(uint64_t n, int grid);   // number of wave regions
 int tile_count(int W, int H);
 // bounds != NULL enables per-chunk frustum culling (see k_project_bin)
 void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const Lists &L,

@@ -13,9 +13,9 @@ namespace rtr {
 
 #define RTR_EMPTY 0x7F7FFFFFu
 constexpr int kBlock = 256;   // 4 waves
-static int g_pt_grid = 1024;  // workgroups of the grid-stride point kernels (4 per CU measured best:
-                              // 1024 -> 205 us, 1536 -> 218, 2048 -> 239 for k_project_bin; 2048 does
-                              // not even fit: its 84 SGPRs admit 7 x 256 threads per CU, not 8)
+// The grid-stride point kernels run Cloud::grid workgroups (kDefaultPointGrid = 1024, i.e. 4
+// per CU, measured best: 1024 -> 205 us, 1536 -> 218, 2048 -> 239 for k_project_bin; 2048 would
+// not even be co-resident: its 84 SGPRs admit 7 x 256 threads per CU, not 8).
 
 // one rounding per operation: plain operators under -ffp-contract=off (hipcc's __fmul_rn &
 // co. are the same plain operators; __fsqrt_rn is NOT correctly rounded, sqrtf is)
@@ -115,15 +115,11 @@ __device__ __forceinline__ uint32_t lds_hist_add(uint32_t *hist, uint32_t key, b
     return res;
 }
 
-static int point_grid(uint64_t n4) {
+static int point_grid(uint64_t n4, int grid) {
     uint64_t blocks = (n4 + kBlock - 1) / kBlock;
-    return (int)(blocks < (uint64_t)g_pt_grid ? blocks : (uint64_t)g_pt_grid);
+    uint64_t cap = grid < 1 ? 1 : (uint64_t)grid;
+    return (int)(blocks < cap ? blocks : cap);
 }
-
-void set_point_grid(int blocks) { g_pt_grid = blocks < 1 ? 1 : blocks; }
-
-static int g_debug_skip = 0;  // timing experiments only (results become wrong): see tools/
-void set_debug_skip(int bits) { g_debug_skip = bits; }
 
 // ---- mode 0: the reference's structure (two full streams + global atomics) -------------
 // A4 minDepthPass (render.cu:53-83).  Semantics = "atomicMin of every surviving point";
@@ -156,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void k_min_depth(const float4 *__restrict__
 void launch_min_depth(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *depth) {
     uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) return;
-    hipLaunchKernelGGL(k_min_depth, dim3(point_grid(n4)), dim3(kBlock), 0, s, (const float4 *)c.x, (const float4 *)c.y,
+    hipLaunchKernelGGL(k_min_depth, dim3(point_grid(n4, c.grid)), dim3(kBlock), 0, s, (const float4 *)c.x, (const float4 *)c.y,
                        (const float4 *)c.z, n4, P, W, H, depth);
 }
 
@@ -199,7 +195,7 @@ void launch_accumulate(hipStream_t s, const Cloud &c, const Proj &P, int W, int 
                        uint32_t *acc, float window) {
     uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) return;
-    hipLaunchKernelGGL(k_accumulate, dim3(point_grid(n4)), dim3(kBlock), 0, s, (const float4 *)c.x, (const float4 *)c.y,
+    hipLaunchKernelGGL(k_accumulate, dim3(point_grid(n4, c.grid)), dim3(kBlock), 0, s, (const float4 *)c.x, (const float4 *)c.y,
                        (const float4 *)c.z, c.rgba, n4, P, W, H, depth, acc, window);
 }
 
@@ -265,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void k_stream_probe(const float4 *__restric
 void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *sink, int variant) {
     uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) return;
-    dim3 g(point_grid(n4)), b(kBlock);
+    dim3 g(point_grid(n4, c.grid)), b(kBlock);
     const float4 *x = (const float4 *)c.x, *y = (const float4 *)c.y, *z = (const float4 *)c.z;
     switch (variant) {
         case 1: hipLaunchKernelGGL(k_stream_probe<1>, g, b, 0, s, x, y, z, n4, P, W, H, sink); break;
@@ -309,7 +305,8 @@ __host__ __device__ inline TileGeom tile_geom(int W, int H) {
     g.tw_shift = 5;
     g.tiles_x = (W + 31) >> 5;
     g.tiles_y = (H + kTileH - 1) / kTileH;
-    if (g.tiles_x * g.tiles_y > 4096) {  // keep the LDS histogram <= 16 KB (4K frames)
+    if (g.tiles_x * g.tiles_y > 4096) {  // keep the LDS histogram <= 16 KB (4K frames); the host falls
+                                         // back to the atomic form when even 64-wide tiles exceed 4096
         g.tw_shift = 6;
         g.tiles_x = (W + 63) >> 6;
     }
@@ -319,16 +316,16 @@ __host__ __device__ inline TileGeom tile_geom(int W, int H) {
 
 int tile_count(int W, int H) { return tile_geom(W, H).ntiles; }
 
-uint64_t list_region_cap(uint64_t n) {  // entries one wave can produce: its iterations x 64 lanes x 4 points
+uint64_t list_region_cap(uint64_t n, int grid) {  // entries one wave can produce: its iterations x 64 lanes x 4 points
     uint64_t n4 = (n + 3) / 4;
     if (n4 == 0) return 0;
-    uint64_t threads = (uint64_t)point_grid(n4) * kBlock;
+    uint64_t threads = (uint64_t)point_grid(n4, grid) * kBlock;
     return ((n4 + threads - 1) / threads) * 256;
 }
 
-uint64_t list_num_waves(uint64_t n) {
+uint64_t list_num_waves(uint64_t n, int grid) {
     uint64_t n4 = (n + 3) / 4;
-    return n4 ? (uint64_t)point_grid(n4) * (kBlock / 64) : 0;
+    return n4 ? (uint64_t)point_grid(n4, grid) * (kBlock / 64) : 0;
 }
 
 // T1 ------------------------------------------------------------------------------
@@ -849,11 +846,11 @@ void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int
     uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) return;
     if (bounds)
-        hipLaunchKernelGGL(k_project_bin<true>, dim3(point_grid(n4)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s,
+        hipLaunchKernelGGL(k_project_bin<true>, dim3(point_grid(n4, c.grid)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s,
                            (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, g, L, tile_hist,
                            blk_hist, bounds);
     else
-        hipLaunchKernelGGL(k_project_bin<false>, dim3(point_grid(n4)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s,
+        hipLaunchKernelGGL(k_project_bin<false>, dim3(point_grid(n4, c.grid)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s,
                            (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, g, L, tile_hist,
                            blk_hist, bounds);
 }
@@ -907,9 +904,9 @@ void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const Lists &L
     uint64_t n4 = (c.n + 3) / 4;
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, B.tile_hist, B.tile_start, B.cursor, B.order, g.ntiles);
     if (n4 == 0) return;
-    hipLaunchKernelGGL(k_scatter<kScatterWPR>, dim3(point_grid(n4)), dim3(kBlock * kScatterWPR),
+    hipLaunchKernelGGL(k_scatter<kScatterWPR>, dim3(point_grid(n4, c.grid)), dim3(kBlock * kScatterWPR),
                        g.ntiles * sizeof(uint32_t), s, L, g.ntiles, g.tw_shift + 5, B.blk_hist, B.cursor, B.entries,
-                       g_debug_skip & 3);
+                       c.debug & 3);
 }
 
 void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const Bins &B, float window, uint32_t *depth,
@@ -922,7 +919,7 @@ void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const Bi
     if (mode == 0)
         hipLaunchKernelGGL(k_tile<0>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, B.order, c.rgba, g,
                            W,
-                           H, window, depth, acc, img, write_acc | ((g_debug_skip >> 2) << 10), pyr ? *pyr : none);
+                           H, window, depth, acc, img, write_acc | ((c.debug >> 2) << 10), pyr ? *pyr : none);
     else if (mode == 1)
         hipLaunchKernelGGL(k_tile<1>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, B.order, c.rgba, g,
                            W,

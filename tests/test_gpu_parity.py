@@ -292,3 +292,35 @@ def test_packed_accumulator_boundary(pkg, orc, projector, mode, n_same):
     xyzw, rgba = cloud(pts, cols)
     ref = _check_frame(pkg, orc, projector, xyzw, rgba, P, 64, 48)
     assert ref["acc"][24, 32, 3] >= n_same and tuple(ref["img"][24, 32]) != (0, 0, 0)
+
+
+def test_frames_larger_than_4k_fall_back(pkg, orc, projector):
+    """More than 4096 screen tiles (beyond 3840x2160): the library silently uses the atomic
+    form; the frame is still exact."""
+    n, W, H = 150_000, 5120, 2880
+    xyzw, rgba = orc.generate("room_shell", 8, 0, n, n)
+    _check_frame(pkg, orc, projector, xyzw, rgba, pkg.orbit_projection(50, W, H), W, H)
+
+
+def test_point_grid_is_per_context(pkg, orc, projector):
+    """The tuning knob "point_grid" sizes a context's candidate lists; changing it on one
+    context must not disturb another (it used to be process-wide)."""
+    n, W, H = 300_000, 640, 480
+    xyzw, rgba = orc.generate("room_shell", 12, 0, n, n)
+    P = pkg.orbit_projection(9, W, H)
+    ref = orc.project(xyzw, rgba, P, W, H)
+    projector.upload_points(xyzw, rgba)
+    projector.set_resolution(W, H)
+    img, _ = projector.project(P)          # lists allocated for the default grid
+    other = pkg.Projector(0)
+    try:
+        other.set_option("point_grid", 37)
+        other.upload_points(xyzw, rgba)
+        other.set_resolution(W, H)
+        img_o, depth_o = other.project(P)
+        img2, depth2 = projector.project(P)  # still the default grid here
+        for i, d in ((img_o, depth_o), (img2, depth2)):
+            assert np.array_equal(i, ref["img"]) and np.array_equal(d.view(np.uint32), ref["depth_bits"])
+        assert np.array_equal(img, ref["img"])
+    finally:
+        other.close()
