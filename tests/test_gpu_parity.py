@@ -324,3 +324,27 @@ def test_point_grid_is_per_context(pkg, orc, projector):
         assert np.array_equal(img, ref["img"])
     finally:
         other.close()
+
+
+def test_adversarial_floats(pkg, orc, projector, mode):
+    """Coordinates drawn from raw bit patterns (inf, nan, denormals, 1e38 ...) mixed with an
+    ordinary cloud: every culling path (r.z sign, conservative frustum test, chunk boxes, exact
+    arithmetic with its correctly rounded reciprocal) must agree with the oracle bit for bit."""
+    rng = np.random.default_rng(123)
+    n, W, H = 60_000, 640, 480
+    wild = rng.integers(0, 2 ** 32, size=(n, 3), dtype=np.uint64).astype(np.uint32).view(np.float32)
+    tame, _ = orc.generate("room_shell", 3, 0, n, n)
+    xyz = np.where(rng.random((n, 1)) < 0.5, wild, tame[:, :3]).astype(np.float32)
+    xyz[::7, 2] = np.float32(1e-41)   # denormal depths right at the camera plane
+    xyz[::11, 0] = np.float32(3e38)
+    rgb = rng.integers(0, 256, size=(n, 3), dtype=np.uint8)
+    xyzw, rgba = cloud(xyz, rgb)
+    projector.set_option("cull", 1)
+    try:
+        for k in (0, 444):
+            _check_frame(pkg, orc, projector, xyzw, rgba, pkg.orbit_projection(k, W, H), W, H)
+        # identity camera: r.z = z, so the denormal / huge depths reach the division unchanged
+        K = np.array([[500.0, 0, 320], [0, 500.0, 240], [0, 0, 1]])
+        _check_frame(pkg, orc, projector, xyzw, rgba, orc.compose_projection(K, np.eye(4)), W, H)
+    finally:
+        projector.set_option("cull", 0)
