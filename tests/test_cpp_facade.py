@@ -47,3 +47,11 @@ def test_facade_matches_oracle(tmp_path, pkg, orc):
     assert np.array_equal(rd(".frgb", np.uint8), rf["img"].reshape(-1))
     assert np.array_equal(rd(".fdepth", np.uint32), rf["depth"].view(np.uint32).reshape(-1))
     assert np.array_equal(rd(".tensor", np.uint16), rf["tensor"].reshape(-1))
+
+
+def test_cpp_example_compiles(tmp_path, pkg):
+    exe = str(tmp_path / "render_trajectory")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "render_trajectory.cpp"), "-o", exe, pkg.LIB_PATH,
+                           "-Wl,-rpath," + os.path.dirname(pkg.LIB_PATH)])
+    assert os.path.exists(exe)

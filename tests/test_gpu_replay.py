@@ -29,8 +29,9 @@ def _read_pfm(path):
         return np.frombuffer(f.read(), np.float32).reshape(h, w)[::-1]
 
 
+@pytest.mark.parametrize("app", ["python", "cpp"])
 @pytest.mark.parametrize("traj_kind,filtered", [("colmap", False), ("tum", True)])
-def test_replay_cli_matches_oracle(pkg, orc, tmp_path, traj_kind, filtered):
+def test_replay_cli_matches_oracle(pkg, orc, tmp_path, traj_kind, filtered, app):
     F = pkg.formats
     n, W, H = 60_000, 640, 480
     xyzw, rgba = orc.generate("room_shell", 0xC0FFEE05, 0, n, n)
@@ -38,6 +39,9 @@ def test_replay_cli_matches_oracle(pkg, orc, tmp_path, traj_kind, filtered):
     cal = pkg.benchmark_calibration(W, H)
     F.write_cameras_txt(tmp_path / "cameras.txt", cal)
     poses = [pkg.orbit_pose(k) for k in (0, 111, 222, 333)]
+    if app == "cpp" and traj_kind == "tum":
+        pytest.skip("the C++ example inverts rigid poses analytically; bit-level agreement with numpy's LU inverse "
+                    "is not guaranteed (parity unpinned at that step: cv::Matx44d::inv, main.cpp:96)")
     if traj_kind == "colmap":
         traj = tmp_path / "images.txt"
         F.write_images_txt(traj, poses)
@@ -47,8 +51,18 @@ def test_replay_cli_matches_oracle(pkg, orc, tmp_path, traj_kind, filtered):
         F.write_trajectory_tum(traj, poses)
         poses_back = F.read_trajectory_tum(traj)
     out = tmp_path / "frames"
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "render_trajectory.py"), str(tmp_path / "cloud.ply"), str(traj),
-           str(tmp_path / "cameras.txt"), "--out", str(out), "--every", "1"] + (["--filtered"] if filtered else [])
+    if app == "python":
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "render_trajectory.py")]
+    else:  # the C++ example on the header-only facade (examples/render_trajectory.cpp)
+        exe = str(tmp_path / "render_trajectory")
+        libdir = os.path.dirname(pkg.LIB_PATH)
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "examples", "render_trajectory.cpp"), "-o", exe, pkg.LIB_PATH,
+                               "-Wl,-rpath," + libdir])
+        out.mkdir()
+        cmd = [exe]
+    cmd += [str(tmp_path / "cloud.ply"), str(traj), str(tmp_path / "cameras.txt"), "--out", str(out), "--every", "1"] \
+        + (["--filtered"] if filtered else [])
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr
     assert "Loaded %d points" % n in res.stdout
