@@ -18,7 +18,8 @@ struct Cloud {
     const uint32_t *rgba;    // packed c0 | c1<<8 | c2<<16 | 255<<24
     uint64_t n;              // real point count
     int grid;                // workgroups of the grid-stride point kernels (lists are sized for it)
-    int debug;               // timing experiments only: bit0/1 T3, bit2/3/4 T4 min/acc/write-out, bit5 no colour gather
+    int debug;               // timing experiments only (frames become wrong): bit1 T3 move, bit2/3/4 T4 min/acc/
+                             // write-out, bit5 T4 no colour gather, bit6 T1 no list stores, bit7 T1 no LDS histogram
 };
 
 struct FilterLevels {

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
                                                         const float4 *__restrict__ z4, uint64_t n4, Proj P, int W,
                                                         int H, TileGeom g, Lists L, uint32_t *__restrict__ tile_hist,
                                                         uint32_t *__restrict__ blk_hist,
-                                                        const float *__restrict__ bounds) {
+                                                        const float *__restrict__ bounds, int dbg) {
     extern __shared__ uint32_t s_hist[];
     for (int t = threadIdx.x; t < g.ntiles; t += kBlock) s_hist[t] = 0;
     __syncthreads();
@@ -412,10 +412,12 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
                 uint32_t tiled = (tile << tshift) | (uint32_t)(((v & 31) << g.tw_shift) | (u & twm));
                 uint32_t pos = fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                my_t[pos] = tiled;
-                my_d[pos] = __float_as_uint(rz[k]);
-                my_i[pos] = (uint32_t)(4 * i + k);
-                lds_hist_add(s_hist, tile, true);  // exec = the in-frustum lanes
+                if (!(dbg & 64)) {
+                    my_t[pos] = tiled;
+                    my_d[pos] = __float_as_uint(rz[k]);
+                    my_i[pos] = (uint32_t)(4 * i + k);
+                }
+                if (!(dbg & 128)) lds_hist_add(s_hist, tile, true);  // exec = the in-frustum lanes
             }
             fill += (uint32_t)__popcll(m);
         }
@@ -848,11 +850,11 @@ void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int
     if (bounds)
         hipLaunchKernelGGL(k_project_bin<true>, dim3(point_grid(n4, c.grid)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s,
                            (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, g, L, tile_hist,
-                           blk_hist, bounds);
+                           blk_hist, bounds, c.debug);
     else
         hipLaunchKernelGGL(k_project_bin<false>, dim3(point_grid(n4, c.grid)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s,
                            (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, g, L, tile_hist,
-                           blk_hist, bounds);
+                           blk_hist, bounds, c.debug);
 }
 
 // bounding box of every 256-point chunk (the unit one wave of T1 handles per iteration):
