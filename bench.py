@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=10_000_000)
     ap.add_argument("--cpu-frames", type=int, default=0, help="0 = pick so the leg takes about 10-20 s")
-    ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity gate on frame 0")
+    ap.add_argument("--no-parity", action="store_true", help="skip the full-size oracle parity gate on pose 0")
     return ap.parse_args()
 
 
@@ -180,16 +180,23 @@ def main():
             colour = "allreduce"
     renderers = make_renderers(colour)
 
-    # parity gate on pose 0 at full size vs the oracle run on the host (bounded: only when
-    # the cloud is small enough to regenerate on the CPU)
+    # parity gate on pose 0 at FULL size: the resident cloud is copied back and projected by the
+    # multi-thread oracle on the host (bounded by host memory: 20 B per point)
     parity = None
-    if rank == 0 and not args.no_parity and world == 1 and total <= 20_000_000:
+    if rank == 0 and not args.no_parity and world == 1 and not multi and total <= 250_000_000:
         orc = entry.load_oracle()
-        xyzw, rgba = orc.generate(args.scene, SEEDS["C3"], 0, total, total)
-        img, depth = proj.project(poses[0])
+        xyzw, rgba = proj.download_points()
+        img, depth = proj.project(poses[0], filtered=with_filter)
         ref = orc.MTProjector(W, H, host_threads()).project(xyzw, rgba, poses[0])
-        parity = bool(np.array_equal(depth.view(np.uint32), ref["depth_bits"]) and np.array_equal(img, ref["img"]))
         del xyzw, rgba
+        rd, ri = ref["depth_bits"], ref["img"]
+        if with_filter:
+            rf = orc.filter(rd, ri)
+            rd, ri = rf["depth"].view(np.uint32), rf["img"]
+            ok_t = np.array_equal(proj.download(pkg._lib.BUF_TENSOR).reshape(5, H, W), rf["tensor"])
+        else:
+            ok_t = True
+        parity = bool(np.array_equal(depth.view(np.uint32), rd) and np.array_equal(img, ri) and ok_t)
 
     for k in range(args.warmup):
         render(renderers, k, poses[k])
