@@ -52,6 +52,8 @@ def parse():
                     help="N=1: independent frames alternate between this many contexts / HIP streams, so the "
                          "latency-bound tail of frame k (tile sort, tile z-buffer, prefilter) overlaps the "
                          "bandwidth-bound stream of frame k+1")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo + several ranks on ONE GPU is a rehearsal of the N>1 logic")
     ap.add_argument("--force-exchange", action="store_true",
                     help="rehearsal on ONE GPU: run the N>1 code path (streams, RCCL collectives in a 1-rank "
                          "group, 2 frames in flight); the numbers are not a benchmark result")
@@ -112,12 +114,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    local_rank = local_rank % max(ndev, 1)  # rehearsal: more ranks than GPUs share devices (gloo only)
     torch.cuda.set_device(local_rank)
     multi = world > 1 or args.force_exchange  # take the exchange code path
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29555")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pkg = entry.load_package()
     W, H = args.width, args.height
@@ -198,6 +205,23 @@ def main():
             ok_t = True
         parity = bool(np.array_equal(depth.view(np.uint32), rd) and np.array_equal(img, ri) and ok_t)
 
+    # N > 1 parity gate (small totals only: the whole cloud is regenerated on rank 0's host)
+    if multi and not args.no_parity and total <= 50_000_000:
+        render(renderers, 0, poses[0])
+        sync()
+        if rank == 0:
+            orc = entry.load_oracle()
+            xyzw, rgba = orc.generate(args.scene, SEEDS["C3"], 0, total, total)
+            ref = orc.MTProjector(W, H, host_threads()).project(xyzw, rgba, poses[0])
+            del xyzw, rgba
+            rd, ri = ref["depth_bits"], ref["img"]
+            if with_filter:
+                rf = orc.filter(rd, ri)
+                rd, ri = rf["depth"].view(np.uint32), rf["img"]
+            parity = bool(np.array_equal(proj.download(pkg._lib.BUF_DEPTH), rd) and
+                          np.array_equal(proj.download(pkg._lib.BUF_IMAGE), ri))
+        sync()
+
     for k in range(args.warmup):
         render(renderers, k, poses[k])
     sync()
@@ -272,8 +296,9 @@ def main():
                                       total, args.scene, W, H, " + depth-heuristic prefilter" if with_filter else ""),
                        "points_total": total, "points_per_gpu": n_local, "scene": args.scene,
                        "resolution": [W, H], "prefilter": with_filter,
-                       "parallelism": ("point-shard x%d, RCCL all-reduce MIN(depth) + %s SUM(accum), %d frames in "
-                                       "flight" % (world, colour, depth_k)) if multi else
+                       "parallelism": ("point-shard x%d, %s all-reduce MIN(depth) + %s SUM(accum), %d frames in "
+                                       "flight" % (world, "RCCL" if args.backend == "nccl" else "gloo", colour,
+                                                   depth_k)) if multi else
                        ("single GPU" + (", %d frames in flight" % depth_k if depth_k > 1 else ""))},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -1,0 +1,38 @@
+"""-m gpu: bench.py's real N > 1 code path with TWO ranks on one GPU (torch.distributed.run,
+gloo backend moving CUDA tensors): point-slice sharding, MIN / SUM exchange, reduce-scatter
+colour form with its self-check, two frames in flight -- and the frame of pose 0 compared with
+the oracle inside bench.py ("parity_vs_oracle").  RCCL itself is covered by test_gpu_rccl.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("extra", [[], ["--scaling", "strong", "--colour", "allreduce", "--pipeline", "1"]],
+                         ids=["weak-rs-pipelined", "strong-allreduce"])
+def test_two_rank_bench_matches_oracle(extra):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend",
+           "gloo", "--points", "3000000", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["parity_vs_oracle"] is True
+    assert out["config"]["points_total"] == (3_000_000 if "strong" in extra else 6_000_000)
+    assert out["roofline"]["bound"] == "hbm" and out["value"] > 0
