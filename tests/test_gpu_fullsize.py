@@ -117,3 +117,25 @@ def test_chunked_upload_roundtrip(pkg, orc):
     finally:
         a.close()
         b.close()
+
+
+@pytest.mark.parametrize("scene", ["room_shell", "uniform_box"])
+def test_trajectory_sweep_against_oracle(pkg, orc, scene):
+    """Every 37th pose of the 1000-pose benchmark orbit at 1e7 points, with and without chunk
+    culling: tile loads, heavy-tile order and the culling boxes change with the view."""
+    n = 10_000_000
+    p = pkg.Projector(0)
+    try:
+        p.generate_synthetic(scene, 0xC0FFEE02, 0, n, n)
+        xyzw, rgba = p.download_points()
+        p.set_resolution(W, H)
+        mt = orc.MTProjector(W, H, _threads())
+        for i, k in enumerate(range(0, 1000, 37)):
+            P = pkg.orbit_projection(k, W, H)
+            ref = mt.project(xyzw, rgba, P)
+            p.set_option("cull", i & 1)
+            img, depth = p.project(P)
+            assert np.array_equal(depth.view(np.uint32), ref["depth_bits"]), (scene, k)
+            assert np.array_equal(img, ref["img"]), (scene, k)
+    finally:
+        p.close()
