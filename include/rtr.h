@@ -69,6 +69,8 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          accumulate + resolve (no global atomics on the frame buffers); 0 = the
  *          reference's structure: two full passes with atomicMin / atomicAdd
  *          (render.cu:53-130).
+ *  "auto_reorder": 1 = every later rtr_upload_points / rtr_generate_synthetic is followed by
+ *          rtr_reorder_points (default 0: the reference's loader already hands over block order).
  *  "cull": 1 = skip 256-point chunks whose bounding box is provably outside the frustum
  *          (exact: same frame; an algorithmic byte reduction, off by default and reported
  *          separately from the roofline figure; needs a spatially coherent point order).

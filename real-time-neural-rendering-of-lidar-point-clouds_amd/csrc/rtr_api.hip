@@ -53,6 +53,7 @@ struct rtr_ctx {
     int opt_keep_accum = 0;     // whole-frame calls also materialise RTR_BUF_ACCUM
     int opt_probe = 0;          // rtr_stream_probe variant (experiments)
     int opt_cull = 0;           // per-chunk frustum culling in T1
+    int opt_auto_reorder = 0;   // Morton-sort every cloud right after upload / generation
     int opt_grid = rtr::kDefaultPointGrid;  // workgroups of the point kernels
     int opt_debug = 0;          // timing experiments (frames become wrong)
 
@@ -332,6 +333,10 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
         c->opt_grid = value;
         return RTR_OK;
     }
+    if (!strcmp(key, "auto_reorder")) {
+        c->opt_auto_reorder = value != 0;
+        return RTR_OK;
+    }
     if (!strcmp(key, "cull")) {
         c->opt_cull = value != 0;
         return RTR_OK;
@@ -425,7 +430,8 @@ int rtr_upload_points(rtr_ctx *c, const float *xyz, size_t xs, const uint8_t *rg
     rtr::launch_pad_nan(c->stream, c->x, c->y, c->z, c->rgba, n, (n + 3) & ~3ull);
     rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return launch_check(c, "aos_to_soa");
+    if (int rc2 = launch_check(c, "aos_to_soa")) return rc2;
+    return c->opt_auto_reorder ? rtr_reorder_points(c) : RTR_OK;
 }
 
 int rtr_generate_synthetic(rtr_ctx *c, int scene, uint64_t seed, uint64_t first, uint64_t count, uint64_t total) {
@@ -442,7 +448,8 @@ int rtr_generate_synthetic(rtr_ctx *c, int scene, uint64_t seed, uint64_t first,
     rtr::launch_pad_nan(c->stream, c->x, c->y, c->z, c->rgba, count, (count + 3) & ~3ull);
     rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return launch_check(c, "generate");
+    if (int rc2 = launch_check(c, "generate")) return rc2;
+    return c->opt_auto_reorder ? rtr_reorder_points(c) : RTR_OK;
 }
 
 int rtr_reorder_points(rtr_ctx *c) {

@@ -348,3 +348,22 @@ def test_adversarial_floats(pkg, orc, projector, mode):
         _check_frame(pkg, orc, projector, xyzw, rgba, orc.compose_projection(K, np.eye(4)), W, H)
     finally:
         projector.set_option("cull", 0)
+
+
+def test_auto_reorder_option(pkg, orc):
+    n, W, H = 100_000, 320, 240
+    xyzw, rgba = orc.generate("uniform_box", 6, 0, n, n)
+    P = pkg.orbit_projection(64, W, H)
+    ref = orc.project(xyzw, rgba, P, W, H)
+    p = pkg.Projector(0)
+    try:
+        p.set_option("auto_reorder", 1)
+        p.set_option("cull", 1)
+        p.upload_points(xyzw, rgba)
+        back, _ = p.download_points()
+        assert not np.array_equal(back, xyzw)  # the resident order is the Morton order now
+        p.set_resolution(W, H)
+        img, depth = p.project(P)
+        assert np.array_equal(img, ref["img"]) and np.array_equal(depth.view(np.uint32), ref["depth_bits"])
+    finally:
+        p.close()
