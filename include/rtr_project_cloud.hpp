@@ -16,6 +16,7 @@
 // Return codes as in project_cloud.cu:268-312: 1 on success, -1 when both outputs are null.
 // Unlike the reference (exit(1) on CUDA errors, project_cloud.cu:13-17) failures throw.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -56,6 +57,27 @@ public:
     int computeFilteredRGBD(const Calibration& calibration, const Extrinsics& extrinsics, Image* color, Image* depth) {
         return frame(calibration, extrinsics, color, depth, true);
     }
+    // literal nullptr for one output, as in cloudreader.cpp:246 `computeRGBD(calib, pose, nullptr, &depth)`
+    template <class Calibration, class Extrinsics, class Image>
+    int computeRGBD(const Calibration& c, const Extrinsics& e, std::nullptr_t, Image* depth) {
+        return frame(c, e, static_cast<Image*>(nullptr), depth, false);
+    }
+    template <class Calibration, class Extrinsics, class Image>
+    int computeRGBD(const Calibration& c, const Extrinsics& e, Image* color, std::nullptr_t) {
+        return frame(c, e, color, static_cast<Image*>(nullptr), false);
+    }
+    template <class Calibration, class Extrinsics>
+    int computeRGBD(const Calibration&, const Extrinsics&, std::nullptr_t, std::nullptr_t) { return -1; }
+    template <class Calibration, class Extrinsics, class Image>
+    int computeFilteredRGBD(const Calibration& c, const Extrinsics& e, std::nullptr_t, Image* depth) {
+        return frame(c, e, static_cast<Image*>(nullptr), depth, true);
+    }
+    template <class Calibration, class Extrinsics, class Image>
+    int computeFilteredRGBD(const Calibration& c, const Extrinsics& e, Image* color, std::nullptr_t) {
+        return frame(c, e, color, static_cast<Image*>(nullptr), true);
+    }
+    template <class Calibration, class Extrinsics>
+    int computeFilteredRGBD(const Calibration&, const Extrinsics&, std::nullptr_t, std::nullptr_t) { return -1; }
     // computeFull (project_cloud.cu:437-493) = computeFilteredRGBD + the caller's U-Net on this
     // device pointer: torch::from_blob(tensor(), {1,5,H,W}, fp16, kCUDA)   (project_cloud.cu:471)
     void* tensor() const {

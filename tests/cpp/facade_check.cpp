@@ -57,7 +57,12 @@ int main(int argc, char** argv) {
         Img rgb, depth;
         rgb.bytes.resize((size_t)W * H * 3); depth.bytes.resize((size_t)W * H * 4);
         if (pc.computeRGBD(cal, E, (Img*)nullptr, (Img*)nullptr) != -1) return 3;
+        if (pc.computeRGBD(cal, E, nullptr, nullptr) != -1) return 3;
+        Img donly;
+        donly.bytes.resize((size_t)W * H * 4);
+        if (pc.computeRGBD(cal, E, nullptr, &donly) != 1) return 3;  // depth-only call of cloudreader.cpp:246
         if (pc.computeRGBD(cal, E, &rgb, &depth) != 1) return 3;
+        if (donly.bytes != depth.bytes) return 6;
         dump(out + ".rgb", rgb.bytes.data(), rgb.bytes.size());
         dump(out + ".depth", depth.bytes.data(), depth.bytes.size());
         if (pc.computeFilteredRGBD(cal, E, &rgb, &depth) != 1) return 3;
