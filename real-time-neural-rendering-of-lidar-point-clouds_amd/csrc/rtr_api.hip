@@ -51,6 +51,9 @@ struct rtr_ctx {
     int opt_mode = 1;           // 0 = two-pass global atomics (the reference's structure),
                                 // 1 = tile-binned LDS z-buffer (default)
     int opt_keep_accum = 0;     // whole-frame calls also materialise RTR_BUF_ACCUM
+    uint32_t *stats_host = nullptr;  // mapped host memory written by the scan kernel: {entries, heaviest tile}
+    uint32_t atomic_frames = 0;      // consecutive whole frames rendered in the atomic form because of a hot tile
+    bool force_atomic = false;       // set around such a frame
     int opt_probe = 0;          // rtr_stream_probe variant (experiments)
     int opt_cull = 0;           // per-chunk frustum culling in T1
     int opt_auto_reorder = 0;   // Morton-sort every cloud right after upload / generation
@@ -287,6 +290,15 @@ int rtr_create(rtr_ctx **out, int device) {
         delete c;
         return rc;
     }
+    e = hipHostMalloc((void **)&c->stats_host, 2 * sizeof(uint32_t), hipHostMallocMapped);
+    if (e == hipSuccess) {
+        c->stats_host[0] = c->stats_host[1] = 0;
+        void *dptr = nullptr;
+        if (hipHostGetDevicePointer(&dptr, c->stats_host, 0) == hipSuccess) c->bins.stats = static_cast<uint32_t *>(dptr);
+    } else {
+        c->stats_host = nullptr;  // optional: without it the hot-tile fallback is simply off
+        (void)hipGetLastError();
+    }
     *out = c;
     return RTR_OK;
 }
@@ -300,6 +312,7 @@ int rtr_destroy(rtr_ctx *c) {
     free_frame(c);
     free_cloud(c);
     dfree(c->minmax);
+    if (c->stats_host) (void)hipHostFree(c->stats_host);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return RTR_OK;
@@ -551,7 +564,9 @@ int rtr_clear(rtr_ctx *c) {
 
 // The binned form keeps one LDS counter per screen tile (<= 4096 tiles: up to 3840 x 2160);
 // larger frames fall back to the atomic form.
-static bool use_tiles(const rtr_ctx *c) { return c->opt_mode == 1 && rtr::tile_count(c->W, c->H) <= 4096; }
+static bool use_tiles(const rtr_ctx *c) {
+    return c->opt_mode == 1 && !c->force_atomic && rtr::tile_count(c->W, c->H) <= 4096;
+}
 
 // T1..T3 of the tile-binned form: stream + candidate lists + tile histogram, scan, scatter
 static int bin_points(rtr_ctx *c, const float P[16]) {
@@ -665,7 +680,19 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
         if (int rc = ensure_pyramid(c)) return rc;
     }
     int rc;
-    if (use_tiles(c)) {  // one launch does clear + min + accumulate + resolve per tile
+    // Hot-tile fallback: T4 gives a whole tile to one workgroup, so a view that packs most of
+    // the cloud into a few tiles (a distant overview) would serialise there.  The scan kernel
+    // reports the heaviest tile of each frame through mapped host memory; it is read here
+    // WITHOUT synchronisation (a frame or two stale -- it only steers speed, both forms produce
+    // the same frame).  While the heaviest tile exceeds 2^18 entries the atomic form is used,
+    // and the binned form is probed again every 16th frame.
+    bool tiles = use_tiles(c);
+    if (tiles && c->stats_host && c->stats_host[1] > (1u << 18)) {
+        if (++c->atomic_frames % 16 != 0) tiles = false;
+    } else {
+        c->atomic_frames = 0;
+    }
+    if (tiles) {  // one launch does clear + min + accumulate + resolve per tile
         DevGuard g(c->device);
         if ((rc = bin_points(c, P))) return rc;
         // with the default four levels the tile kernel also emits the prefilter's pyramid and
@@ -687,10 +714,13 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
         if (with_filter) return filter_impl(c, pyr.enable ? rtr::tile_count(c->W, c->H) : 0);
         return RTR_OK;
     } else {
-        if ((rc = rtr_clear(c))) return rc;
-        if ((rc = rtr_min_depth_pass(c, P))) return rc;
-        if ((rc = rtr_accumulate_pass(c, P))) return rc;
-        if ((rc = rtr_resolve(c))) return rc;
+        c->force_atomic = true;  // the phase calls below must not take the binned form either
+        rc = rtr_clear(c);
+        if (!rc) rc = rtr_min_depth_pass(c, P);
+        if (!rc) rc = rtr_accumulate_pass(c, P);
+        if (!rc) rc = rtr_resolve(c);
+        c->force_atomic = false;
+        if (rc) return rc;
     }
     if (with_filter && (rc = rtr_filter(c))) return rc;
     return RTR_OK;

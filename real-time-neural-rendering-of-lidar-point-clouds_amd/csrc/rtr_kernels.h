@@ -47,6 +47,7 @@ struct Bins {
     Entry *entries;                             // entries counting-sorted by tile
     uint32_t *tile_hist, *tile_start, *cursor;  // [ntiles], [ntiles + 1], [ntiles]
     uint32_t *order;                            // [ntiles]: tile launch order of T4, heavy tiles first
+    uint32_t *stats;                            // [2] in mapped HOST memory: entries of the frame, of its heaviest tile
     uint32_t *blk_hist;                         // [point-grid workgroups][ntiles]: T1's per-workgroup counts
 };
 

@@ -492,7 +492,7 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
 // histogram is re-zeroed for the next frame.  One workgroup of 1024 threads.
 __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *__restrict__ tile_hist, uint32_t *__restrict__ tile_start,
                                                     uint32_t *__restrict__ cursor, uint32_t *__restrict__ order,
-                                                    int ntiles) {
+                                                    uint32_t *__restrict__ stats, int ntiles) {
     __shared__ uint32_t s_part[1024];
     const int per = (ntiles + 1023) / 1024;  // <= 4 (ntiles <= 4096)
     const int lo = threadIdx.x * per;
@@ -512,6 +512,17 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *__restrict__ tile_
             __syncthreads();
         }
     };
+    auto scan_max = [&](uint32_t mine) {  // workgroup max, result in s_part[0]
+        s_part[threadIdx.x] = mine;
+        __syncthreads();
+        for (int off = 512; off > 0; off >>= 1) {
+            if (threadIdx.x < (unsigned)off) {
+                uint32_t o = s_part[threadIdx.x + off];
+                if (o > s_part[threadIdx.x]) s_part[threadIdx.x] = o;
+            }
+            __syncthreads();
+        }
+    };
     scan(sum);
     const uint32_t total = s_part[1023];
     uint32_t run = s_part[threadIdx.x] - sum;  // exclusive prefix of this thread's chunk
@@ -524,6 +535,18 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *__restrict__ tile_
         }
     if (threadIdx.x == 1023) tile_start[ntiles] = total;
     __syncthreads();
+    // frame statistics for the host (mapped host memory, read without synchronisation): total
+    // entries and the entry count of the heaviest tile (one workgroup owns a whole tile in T4)
+    {
+        uint32_t mx = 0;
+        for (int k = 0; k < per && k < 4; ++k) mx = cnt[k] > mx ? cnt[k] : mx;
+        scan_max(mx);
+        if (threadIdx.x == 0 && stats) {
+            stats[0] = total;
+            stats[1] = s_part[0];
+        }
+        __syncthreads();
+    }
     // launch order of the tile kernel: tiles with more than twice the mean entry count first,
     // so the few heavy tiles that bound T4 start at once instead of trailing the launch
     const uint32_t thr = 2u * (total / (uint32_t)ntiles) + 1u;
@@ -904,7 +927,8 @@ void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds) {
 void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const Lists &L, const Bins &B) {
     TileGeom g = tile_geom(W, H);
     uint64_t n4 = (c.n + 3) / 4;
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, B.tile_hist, B.tile_start, B.cursor, B.order, g.ntiles);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, B.tile_hist, B.tile_start, B.cursor, B.order, B.stats,
+                       g.ntiles);
     if (n4 == 0) return;
     hipLaunchKernelGGL(k_scatter<kScatterWPR>, dim3(point_grid(n4, c.grid)), dim3(kBlock * kScatterWPR),
                        g.ntiles * sizeof(uint32_t), s, L, g.ntiles, g.tw_shift + 5, B.blk_hist, B.cursor, B.entries,

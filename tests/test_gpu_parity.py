@@ -367,3 +367,28 @@ def test_auto_reorder_option(pkg, orc):
         assert np.array_equal(img, ref["img"]) and np.array_equal(depth.view(np.uint32), ref["depth_bits"])
     finally:
         p.close()
+
+
+def test_hot_tile_fallback_sequence(pkg, orc, projector):
+    """A run of frames whose points all fall into one tile: after the first such frame the library
+    switches whole-frame renders to the atomic form (steered by un-synchronised statistics from
+    the scan kernel) and probes the binned form every 16th frame; every frame stays exact, and
+    so does the return to an ordinary view."""
+    rng = np.random.default_rng(31)
+    n = 400_000
+    xyz = np.stack([rng.uniform(-0.05, 0.05, n), rng.uniform(-0.05, 0.05, n), rng.uniform(1.9, 2.1, n)], axis=1)
+    rgb = rng.integers(0, 256, size=(n, 3), dtype=np.uint8)
+    xyzw, rgba = cloud(xyz.astype(np.float32), rgb)
+    P_hot = kat_P(orc)                    # everything lands in a 10x10 pixel patch
+    K = np.array([[4000.0, 0, 32], [0, 4000.0, 24], [0, 0, 1]])
+    P_wide = orc.compose_projection(K, np.eye(4))  # zoomed in: spread over the whole 64x48 frame
+    projector.upload_points(xyzw, rgba)
+    projector.set_resolution(64, 48)
+    refs = {id(P): orc.project(xyzw, rgba, P, 64, 48) for P in (P_hot, P_wide)}
+    for k in range(40):
+        P = P_hot if k < 34 else P_wide
+        img, depth = projector.project(P)
+        projector.synchronize()
+        ref = refs[id(P)]
+        assert np.array_equal(depth.view(np.uint32), ref["depth_bits"]), k
+        assert np.array_equal(img, ref["img"]), k
