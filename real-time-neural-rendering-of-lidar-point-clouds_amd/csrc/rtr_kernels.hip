@@ -121,6 +121,66 @@ static int point_grid(uint64_t n4, int grid) {
     return (int)(blocks < cap ? blocks : cap);
 }
 
+// Wave-level aggregation of same-pixel atomics: what the reference does with
+// __match_any_sync / __reduce_*_sync on 32-lane warps (render.cu:74-82,113-128), rebuilt for
+// wave64 without a match instruction: up to four "leader" rounds (stopped as soon as a group has
+// fewer than 8 lanes) -- take the first pending
+// lane's pixel, ballot the lanes that share it, reduce their values with xor-shuffles, let the
+// leader issue ONE atomic -- then whatever is left (incoherent input) goes out lane by lane.
+// Must be called by all lanes of the wave (wave-uniform control flow).
+__device__ __forceinline__ void wave_min(uint32_t *__restrict__ depth, int pix, bool valid, uint32_t bits) {
+    unsigned long long todo = __ballot(valid);
+    if (todo == 0ull) return;
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int round = 0; round < 4 && __popcll(todo) >= 8; ++round) {  // few pending lanes: not worth a round
+        const int first = __ffsll((long long)todo) - 1;
+        const int lead = __builtin_amdgcn_readlane(pix, first);
+        const bool grp = valid && pix == lead;
+        uint32_t v = grp ? bits : 0xFFFFFFFFu;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            uint32_t o = __shfl_xor(v, off, 64);
+            v = o < v ? o : v;
+        }
+        if (lane == first) atomicMin(&depth[lead], v);  // render.cu:81
+        const unsigned long long gm = __ballot(grp);
+        todo &= ~gm;
+        valid = valid && !grp;
+        if (__popcll(gm) < 8) break;  // small groups: the input is not pixel-coherent, rounds do not pay
+    }
+    if (valid) atomicMin(&depth[pix], bits);
+}
+
+// colour: the group's (sum c0, sum c1, sum c2, count) fit one 64-bit word (<= 64 lanes x 255)
+__device__ __forceinline__ void acc_add(uint32_t *__restrict__ acc, int pix, uint32_t c);
+__device__ __forceinline__ void wave_acc(uint32_t *__restrict__ acc, int pix, bool valid, uint32_t c) {
+    unsigned long long todo = __ballot(valid);
+    if (todo == 0ull) return;
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int round = 0; round < 4 && __popcll(todo) >= 8; ++round) {  // few pending lanes: not worth a round
+        const int first = __ffsll((long long)todo) - 1;
+        const int lead = __builtin_amdgcn_readlane(pix, first);
+        const bool grp = valid && pix == lead;
+        unsigned long long v = grp ? ((unsigned long long)(c & 0xFFu) | ((unsigned long long)((c >> 8) & 0xFFu) << 16) |
+                                      ((unsigned long long)((c >> 16) & 0xFFu) << 32) | (1ull << 48))
+                                   : 0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == first) {  // render.cu:125-128 as two 64-bit adds on the 4 x u32 layout
+            unsigned long long *a = reinterpret_cast<unsigned long long *>(acc) + 2 * (size_t)lead;
+            atomicAdd(a + 0, (v & 0xFFFFull) | (((v >> 16) & 0xFFFFull) << 32));
+            atomicAdd(a + 1, ((v >> 32) & 0xFFFFull) | ((v >> 48) << 32));
+        }
+        const unsigned long long gm = __ballot(grp);
+        todo &= ~gm;
+        valid = valid && !grp;
+        if (__popcll(gm) < 8) break;  // small groups: the input is not pixel-coherent, rounds do not pay
+    }
+    if (valid) acc_add(acc, pix, c);
+}
+
 // ---- mode 0: the reference's structure (two full streams + global atomics) -------------
 // A4 minDepthPass (render.cu:53-83).  Semantics = "atomicMin of every surviving point";
 // the reference's __match_any_sync aggregation is only a contention trick.  Early-z: the
@@ -134,8 +194,12 @@ __global__ __launch_bounds__(kBlock) void k_min_depth(const float4 *__restrict__
     const float fW = (float)W, fH = (float)H;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const int lane = threadIdx.x & 63;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
-        Quad q = project_quad(x4, y4, z4, i, P, W, H, fW, fH);
+    // wave-uniform trip count: every lane runs every iteration (the wave-level aggregation below
+    // shuffles across all 64 lanes); lanes past the end re-read the wave's first quad, masked out
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i - (uint64_t)lane < n4; i += stride) {
+        const bool live = i < n4;
+        Quad q = project_quad(x4, y4, z4, live ? i : i - (uint64_t)lane, P, W, H, fW, fH);
+        if (!live) q.pix[0] = q.pix[1] = q.pix[2] = q.pix[3] = -1;
         bool any = (q.pix[0] & q.pix[1] & q.pix[2] & q.pix[3]) >= 0;  // some sign bit clear
         if (__ballot(any) == 0ull) continue;                          // wave-uniform skip
         uint32_t cur[4];
@@ -144,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void k_min_depth(const float4 *__restrict__
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             uint32_t b = __float_as_uint(q.d[k]);
-            if (q.pix[k] >= 0 && b < cur[k]) atomicMin(&depth[q.pix[k]], b);
+            wave_min(depth, q.pix[k], q.pix[k] >= 0 && b < cur[k], b);
         }
     }
 }
@@ -176,18 +240,24 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const float4 *__restrict_
     const float fW = (float)W, fH = (float)H;
     const int lane = threadIdx.x & 63;
     uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
-        Quad q = project_quad(x4, y4, z4, i, P, W, H, fW, fH);
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i - (uint64_t)lane < n4; i += stride) {
+        const bool live = i < n4;  // wave-uniform trip count, see k_min_depth
+        Quad q = project_quad(x4, y4, z4, live ? i : i - (uint64_t)lane, P, W, H, fW, fH);
+        if (!live) q.pix[0] = q.pix[1] = q.pix[2] = q.pix[3] = -1;
         bool any = (q.pix[0] & q.pix[1] & q.pix[2] & q.pix[3]) >= 0;
         if (__ballot(any) == 0ull) continue;
         uint32_t m[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) m[k] = depth[q.pix[k] >= 0 ? q.pix[k] : lane];
+        bool hit[4];
+        uint32_t col[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (q.pix[k] >= 0 && !(q.d[k] > f_add(__uint_as_float(m[k]), window)))  // render.cu:106
-                acc_add(acc, q.pix[k], rgba[4 * i + k]);
+        for (int k = 0; k < 4; ++k) {  // the four colour loads in flight together
+            hit[k] = q.pix[k] >= 0 && !(q.d[k] > f_add(__uint_as_float(m[k]), window));  // render.cu:106
+            col[k] = hit[k] ? rgba[4 * i + k] : 0u;
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wave_acc(acc, q.pix[k], hit[k], col[k]);
     }
 }
 
