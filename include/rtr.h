@@ -75,7 +75,13 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          (exact: same frame; an algorithmic byte reduction, off by default and reported
  *          separately from the roofline figure; needs a spatially coherent point order).
  *  "keep_accum": 1 = the whole-frame calls also write RTR_BUF_ACCUM (default 0; the phase
- *          calls always do). */
+ *          calls always do).
+ *  "overlap": 1 = rtr_render queues the point stream (T1) of a frame on a second, internal
+ *          stream and alternates between two list / bin sets, so it may run beside the tail of
+ *          the previous frame; results are still ordered on the context's stream.  Default 0:
+ *          on MI355X the gain is 0-3 % ("Overlap").  "tail_cus" = t (0..31, set
+ *          before "overlap") additionally gives the two streams disjoint CU masks, t CUs of every
+ *          XCD for the tail; "front_low_priority" = 1 creates the T1 stream at the lowest priority. */
 int rtr_set_option(rtr_ctx *ctx, const char *key, int value);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's
  * own non-blocking stream; NULL means HIP's default stream.  rtr_reset_stream returns to the

@@ -41,11 +41,24 @@ struct rtr_ctx {
     int lv_levels = 0;  // levels the pyramid was allocated for
 
     // tile-binned pipeline: wave-private candidate lists (T1) and their tile-sorted copy (T3)
-    rtr::Lists lists{};
-    rtr::Bins bins{};
-    uint64_t list_n = 0;        // point count the list / bin buffers were sized for
-    int tiles_n = 0;            // tile count the histogram buffers were sized for
-    size_t blk_hist_n = 0;      // elements blk_hist was sized for
+    // (two sets: with option "overlap" T1 of frame k+1 fills one set on the front stream while the
+    // tail of frame k still reads the other)
+    struct FrontSet {
+        rtr::Lists lists{};
+        rtr::Bins bins{};
+        uint64_t list_n = 0;        // point count the list / bin buffers were sized for
+        int tiles_n = 0;            // tile count the histogram buffers were sized for
+        size_t blk_hist_n = 0;      // elements blk_hist was sized for
+        hipEvent_t binned = nullptr, consumed = nullptr;  // T1 done (front stream) / T4 done (tail stream)
+        bool consumed_valid = false;
+    } fs[2];
+    int cur = 0;
+    FrontSet &F() { return fs[cur]; }
+    int opt_overlap = 0;        // whole-frame renders run T1 on `front`, everything else on `stream`
+    int opt_front_prio = 0;     // front stream at the lowest priority (experiment)
+    int opt_tail_cus = 0;       // CUs per XCD reserved for the tail stream when overlapping (0 = no CU masks)
+    hipStream_t front = nullptr;
+    hipStream_t masked_tail = nullptr;
     bool list_valid = false;    // bins match list_P / current cloud / resolution / window
     float list_P[12] = {0};
     int opt_mode = 1;           // 0 = two-pass global atomics (the reference's structure),
@@ -108,17 +121,22 @@ void free_frame(rtr_ctx *c) {
     c->list_valid = false;
     dfree(c->depth); dfree(c->acc); dfree(c->img); dfree(c->mask); dfree(c->part_min); dfree(c->part_max); dfree(c->tensor);
     for (int i = 1; i <= 8; ++i) dfree(c->lv.lv[i]);
-    dfree(c->bins.tile_hist); dfree(c->bins.tile_start); dfree(c->bins.cursor); dfree(c->bins.order); dfree(c->bins.blk_hist);
-    c->tiles_n = 0; c->blk_hist_n = 0;
+    for (auto &f : c->fs) {
+        dfree(f.bins.tile_hist); dfree(f.bins.tile_start); dfree(f.bins.cursor); dfree(f.bins.order); dfree(f.bins.blk_hist);
+        f.tiles_n = 0; f.blk_hist_n = 0;
+    }
     c->lv.lv[0] = nullptr;
     c->W = c->H = 0;
     c->lv_levels = 0;
 }
 
 void free_lists(rtr_ctx *c) {
-    dfree(c->lists.tiled); dfree(c->lists.depth); dfree(c->lists.idx); dfree(c->lists.counts);
-    dfree(c->bins.entries);
-    c->list_n = 0; c->list_valid = false;
+    for (auto &f : c->fs) {
+        dfree(f.lists.tiled); dfree(f.lists.depth); dfree(f.lists.idx); dfree(f.lists.counts);
+        dfree(f.bins.entries);
+        f.list_n = 0;
+    }
+    c->list_valid = false;
 }
 
 void free_cloud(rtr_ctx *c) {
@@ -127,34 +145,38 @@ void free_cloud(rtr_ctx *c) {
     c->n = c->cap = 0;
 }
 
-int ensure_tiles(rtr_ctx *c) {
+int ensure_tiles(rtr_ctx *c, hipStream_t s) {  // s: the stream T1 will run on
     int nt = rtr::tile_count(c->W, c->H);
-    if (c->bins.tile_hist && c->tiles_n == nt) return RTR_OK;
-    dfree(c->bins.tile_hist); dfree(c->bins.tile_start); dfree(c->bins.cursor); dfree(c->bins.order);
-    HIP_TRY(c, hipMalloc((void **)&c->bins.tile_hist, (size_t)nt * 4));
-    HIP_TRY(c, hipMalloc((void **)&c->bins.tile_start, (size_t)(nt + 1) * 4));
-    HIP_TRY(c, hipMalloc((void **)&c->bins.cursor, (size_t)nt * 4));
-    HIP_TRY(c, hipMalloc((void **)&c->bins.order, (size_t)nt * 4));
-    HIP_TRY(c, hipMemsetAsync(c->bins.tile_hist, 0, (size_t)nt * 4, c->stream));
-    c->tiles_n = nt;
+    if (c->F().bins.tile_hist && c->F().tiles_n == nt) return RTR_OK;
+    dfree(c->F().bins.tile_hist); dfree(c->F().bins.tile_start); dfree(c->F().bins.cursor); dfree(c->F().bins.order);
+    HIP_TRY(c, hipMalloc((void **)&c->F().bins.tile_hist, (size_t)nt * 4));
+    HIP_TRY(c, hipMalloc((void **)&c->F().bins.tile_start, (size_t)(nt + 1) * 4));
+    HIP_TRY(c, hipMalloc((void **)&c->F().bins.cursor, (size_t)nt * 4));
+    HIP_TRY(c, hipMalloc((void **)&c->F().bins.order, (size_t)nt * 4));
+    HIP_TRY(c, hipMemsetAsync(c->F().bins.tile_hist, 0, (size_t)nt * 4, s));
+    c->F().tiles_n = nt;
     return RTR_OK;
 }
 
 // Worst-case reservations: a wave region holds every point its wave can see, so list space
 // needs neither atomics nor overflow handling (2 x 12 B x N; sized for a 288 GB part).
 int ensure_lists(rtr_ctx *c) {
-    if (c->lists.tiled && c->list_n == c->n) return RTR_OK;
-    free_lists(c);
+    if (c->F().lists.tiled && c->F().list_n == c->n) return RTR_OK;
+    {
+        auto &f = c->F();
+        dfree(f.lists.tiled); dfree(f.lists.depth); dfree(f.lists.idx); dfree(f.lists.counts); dfree(f.bins.entries);
+        c->list_valid = false;
+    }
     uint64_t waves = rtr::list_num_waves(c->n, c->opt_grid), cap = rtr::list_region_cap(c->n, c->opt_grid);
-    c->lists.region_cap = cap;
-    c->list_n = c->n;
+    c->F().lists.region_cap = cap;
+    c->F().list_n = c->n;
     if (waves == 0) return RTR_OK;
     size_t bytes = waves * cap * sizeof(uint32_t);
-    HIP_TRY(c, hipMalloc((void **)&c->lists.tiled, bytes));
-    HIP_TRY(c, hipMalloc((void **)&c->lists.depth, bytes));
-    HIP_TRY(c, hipMalloc((void **)&c->lists.idx, bytes));
-    HIP_TRY(c, hipMalloc((void **)&c->lists.counts, waves * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void **)&c->bins.entries, waves * cap * sizeof(rtr::Entry)));
+    HIP_TRY(c, hipMalloc((void **)&c->F().lists.tiled, bytes));
+    HIP_TRY(c, hipMalloc((void **)&c->F().lists.depth, bytes));
+    HIP_TRY(c, hipMalloc((void **)&c->F().lists.idx, bytes));
+    HIP_TRY(c, hipMalloc((void **)&c->F().lists.counts, waves * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->F().bins.entries, waves * cap * sizeof(rtr::Entry)));
     return RTR_OK;
 }
 
@@ -183,9 +205,9 @@ rtr::Proj make_proj(const float P[16]) {
 
 rtr::Cloud cloud_of(const rtr_ctx *c) { return rtr::Cloud{c->x, c->y, c->z, c->rgba, c->n, c->opt_grid, c->opt_debug}; }
 
-struct Timed {  // brackets one phase with hipEvents on the context's stream
-    rtr_ctx *c; int k; hipEvent_t a = nullptr, b = nullptr;
-    Timed(rtr_ctx *c_, int k_) : c(c_), k(k_) {
+struct Timed {  // brackets one phase with hipEvents on the stream it is launched on
+    rtr_ctx *c; int k; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    Timed(rtr_ctx *c_, int k_, hipStream_t s_ = nullptr) : c(c_), k(k_), s(s_ ? s_ : c_->stream) {
         if (!c->timing) return;
         if (c->timing == 2 && k != RTR_K_MIN_DEPTH && k != RTR_K_ACCUMULATE) return;
         if (c->pool.empty()) {
@@ -193,18 +215,35 @@ struct Timed {  // brackets one phase with hipEvents on the context's stream
         } else {
             a = c->pool.back().first; b = c->pool.back().second; c->pool.pop_back();
         }
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, s);
     }
     ~Timed() {
         if (!a) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, s);
         c->pending.push_back({a, b, k});
     }
 };
 
+// everything queued by this context is finished (the tail stream waits for the front stream's
+// T1 of every frame it completes, so the order below drains both)
+hipError_t sync_streams(rtr_ctx *c) {
+    if (c->front) {
+        hipError_t e = hipStreamSynchronize(c->front);
+        if (e != hipSuccess) return e;
+    }
+    return hipStreamSynchronize(c->stream);
+}
+
+// after the last reader of the active list / bin set has been queued on the tail stream
+void mark_consumed(rtr_ctx *c) {
+    if (!c->front) return;
+    auto &f = c->F();
+    if (hipEventRecord(f.consumed, c->stream) == hipSuccess) f.consumed_valid = true;
+}
+
 int collect_timing(rtr_ctx *c) {
     if (c->pending.empty()) return RTR_OK;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_streams(c));
     for (auto &s : c->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
@@ -251,6 +290,8 @@ int ensure_pyramid(rtr_ctx *c) {
 
 }  // namespace
 
+static int set_overlap(rtr_ctx *c, bool on);
+
 extern "C" {
 
 int rtr_abi_version(void) { return RTR_ABI_VERSION; }
@@ -294,7 +335,8 @@ int rtr_create(rtr_ctx **out, int device) {
     if (e == hipSuccess) {
         c->stats_host[0] = c->stats_host[1] = 0;
         void *dptr = nullptr;
-        if (hipHostGetDevicePointer(&dptr, c->stats_host, 0) == hipSuccess) c->bins.stats = static_cast<uint32_t *>(dptr);
+        if (hipHostGetDevicePointer(&dptr, c->stats_host, 0) == hipSuccess)
+            for (auto &f : c->fs) f.bins.stats = static_cast<uint32_t *>(dptr);
     } else {
         c->stats_host = nullptr;  // optional: without it the hot-tile fallback is simply off
         (void)hipGetLastError();
@@ -306,8 +348,9 @@ int rtr_create(rtr_ctx **out, int device) {
 int rtr_destroy(rtr_ctx *c) {
     if (!c) return RTR_OK;
     DevGuard g(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)sync_streams(c);
     (void)collect_timing(c);
+    (void)set_overlap(c, false);
     for (auto &p : c->pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     free_frame(c);
     free_cloud(c);
@@ -329,6 +372,69 @@ int rtr_set_params(rtr_ctx *c, const rtr_params *p) {
     return RTR_OK;
 }
 
+// Option "overlap": whole-frame renders put T1 on a second stream and alternate between two
+// list / bin sets, so the HBM-bound stream of frame k+1 runs beside the latency-bound tail of
+// frame k.  With "tail_cus" = t > 0 the two streams get disjoint CU masks (t CUs of every XCD for
+// the tail, the rest for T1) so neither takes the other's wave slots.  The bit -> CU mapping of a
+// mask is not documented for 8-XCD parts (XCD-interleaved or XCD-blocked); the pattern below
+// gives every XCD exactly t tail CUs under both numberings.
+static int set_overlap(rtr_ctx *c, bool on) {
+    DevGuard g(c->device);
+    HIP_TRY(c, sync_streams(c));
+    (void)collect_timing(c);
+    if (!on) {
+        if (c->masked_tail && c->stream == c->masked_tail) c->stream = c->own_stream;
+        if (c->front) (void)hipStreamDestroy(c->front);
+        if (c->masked_tail) (void)hipStreamDestroy(c->masked_tail);
+        c->front = c->masked_tail = nullptr;
+        for (auto &f : c->fs) {
+            if (f.binned) (void)hipEventDestroy(f.binned);
+            if (f.consumed) (void)hipEventDestroy(f.consumed);
+            f.binned = f.consumed = nullptr;
+            f.consumed_valid = false;
+        }
+        c->opt_overlap = 0;
+        return RTR_OK;
+    }
+    if (c->opt_overlap) return RTR_OK;
+    int ncu = 0;
+    HIP_TRY(c, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
+    if (c->opt_tail_cus > 0) {
+        if (ncu != 256) return fail(c, RTR_ERR_UNSUPPORTED, "tail_cus needs the 256-CU / 8-XCD part (device has %d CUs)", ncu);
+        uint32_t tail[8] = {0}, head[8] = {0};
+        for (int i = 0; i < 256; ++i) {
+            int a = i % 8, b = (i / 8) % 4, x = i / 32;
+            bool is_tail = b * 8 + (a + x) % 8 < c->opt_tail_cus;
+            (is_tail ? tail : head)[i / 32] |= 1u << (i % 32);
+        }
+        HIP_TRY(c, hipExtStreamCreateWithCUMask(&c->front, 8, head));
+        hipError_t e = hipExtStreamCreateWithCUMask(&c->masked_tail, 8, tail);
+        if (e != hipSuccess) {
+            (void)hipStreamDestroy(c->front);
+            c->front = nullptr;
+            return fail(c, RTR_ERR_HIP, "hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e));
+        }
+        if (c->stream == c->own_stream) c->stream = c->masked_tail;
+    } else {
+        int lo = 0, hi = 0;  // numerically lowest = highest priority
+        HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(c, hipStreamCreateWithPriority(&c->front, hipStreamNonBlocking, c->opt_front_prio ? lo : 0));
+    }
+    for (auto &f : c->fs) {
+        hipError_t e = hipEventCreateWithFlags(&f.binned, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&f.consumed, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            int rc = fail(c, RTR_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+            c->opt_overlap = 1;  // so that the teardown below runs
+            (void)set_overlap(c, false);
+            return rc;
+        }
+        f.consumed_valid = false;
+    }
+    c->opt_overlap = 1;
+    return RTR_OK;
+}
+
 int rtr_set_option(rtr_ctx *c, const char *key, int value) {
     if (!c) return RTR_ERR_INVALID;
     NEED(c, key != nullptr, "key is NULL");
@@ -341,7 +447,7 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
     if (!strcmp(key, "point_grid")) {
         NEED(c, value >= 1 && value <= 65535, "point_grid out of range");
         DevGuard g(c->device);
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, sync_streams(c));
         free_lists(c);
         c->opt_grid = value;
         return RTR_OK;
@@ -362,6 +468,18 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
         c->opt_probe = value;
         return RTR_OK;
     }
+    if (!strcmp(key, "tail_cus")) {  // takes effect when "overlap" is switched on
+        NEED(c, value >= 0 && value < 32, "tail_cus must be in 0..31 (CUs per XCD)");
+        NEED(c, !c->opt_overlap, "set tail_cus before overlap");
+        c->opt_tail_cus = value;
+        return RTR_OK;
+    }
+    if (!strcmp(key, "front_low_priority")) {
+        NEED(c, !c->opt_overlap, "set front_low_priority before overlap");
+        c->opt_front_prio = value != 0;
+        return RTR_OK;
+    }
+    if (!strcmp(key, "overlap")) return set_overlap(c, value != 0);
     if (!strcmp(key, "keep_accum")) {
         c->opt_keep_accum = value != 0;
         return RTR_OK;
@@ -386,7 +504,7 @@ int rtr_get_params(const rtr_ctx *c, rtr_params *p) {
 
 static int switch_stream(rtr_ctx *c, hipStream_t s) {
     DevGuard g(c->device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_streams(c));
     (void)collect_timing(c);
     c->stream = s;
     return RTR_OK;
@@ -399,13 +517,13 @@ int rtr_set_stream(rtr_ctx *c, void *s) {  // NULL is HIP's default stream, a va
 
 int rtr_reset_stream(rtr_ctx *c) {
     if (!c) return RTR_ERR_INVALID;
-    return switch_stream(c, c->own_stream);
+    return switch_stream(c, c->masked_tail ? c->masked_tail : c->own_stream);
 }
 
 int rtr_synchronize(rtr_ctx *c) {
     if (!c) return RTR_ERR_INVALID;
     DevGuard g(c->device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_streams(c));
     return RTR_OK;
 }
 
@@ -418,7 +536,7 @@ int rtr_upload_points(rtr_ctx *c, const float *xyz, size_t xs, const uint8_t *rg
     NEED(c, rs >= 3, "rgb_stride_bytes must be >= 3");
     NEED(c, n < (1ull << 32), "too many points for one context (point indices are 32-bit): shard the cloud");
     DevGuard g(c->device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_streams(c));
     int rc = alloc_cloud(c, n);
     if (rc) return rc;
     // stage through device chunks; AoS -> SoA on the GPU
@@ -438,11 +556,11 @@ int rtr_upload_points(rtr_ctx *c, const float *xyz, size_t xs, const uint8_t *rg
         HIP_TRY(c, hipMemcpyAsync(sx, (const uint8_t *)xyz + off * xs, cnt * xs, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(sc, rgb + off * rs, cnt * rs, hipMemcpyHostToDevice, c->stream));
         rtr::launch_aos_to_soa(c->stream, sx, xs, sc, rs, cnt, c->x + off, c->y + off, c->z + off, c->rgba + off);
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, sync_streams(c));
     }
     rtr::launch_pad_nan(c->stream, c->x, c->y, c->z, c->rgba, n, (n + 3) & ~3ull);
     rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_streams(c));
     if (int rc2 = launch_check(c, "aos_to_soa")) return rc2;
     return c->opt_auto_reorder ? rtr_reorder_points(c) : RTR_OK;
 }
@@ -454,13 +572,13 @@ int rtr_generate_synthetic(rtr_ctx *c, int scene, uint64_t seed, uint64_t first,
     NEED(c, total < (1ull << 33), "total too large");
     NEED(c, count < (1ull << 32), "too many points for one context (point indices are 32-bit): shard the cloud");
     DevGuard g(c->device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_streams(c));
     int rc = alloc_cloud(c, count);
     if (rc) return rc;
     rtr::launch_generate(c->stream, scene, seed, first, count, total, c->x, c->y, c->z, c->rgba);
     rtr::launch_pad_nan(c->stream, c->x, c->y, c->z, c->rgba, count, (count + 3) & ~3ull);
     rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_streams(c));
     if (int rc2 = launch_check(c, "generate")) return rc2;
     return c->opt_auto_reorder ? rtr_reorder_points(c) : RTR_OK;
 }
@@ -468,12 +586,12 @@ int rtr_generate_synthetic(rtr_ctx *c, int scene, uint64_t seed, uint64_t first,
 int rtr_reorder_points(rtr_ctx *c) {
     if (!c) return RTR_ERR_INVALID;
     DevGuard g(c->device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_streams(c));
     c->list_valid = false;
     int e = rtr::reorder_morton(c->stream, c->x, c->y, c->z, c->rgba, c->n);
     if (e != 0) return fail(c, RTR_ERR_HIP, "reorder failed: %s", hipGetErrorString((hipError_t)e));
     rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_streams(c));
     return launch_check(c, "reorder");
 }
 
@@ -500,7 +618,7 @@ int rtr_download_points(rtr_ctx *c, float *xyzw, uint8_t *rgba, uint64_t first, 
         rtr::launch_soa_to_aos(c->stream, c->x + s0, c->y + s0, c->z + s0, c->rgba + s0, cnt, dx, dc);
         HIP_TRY(c, hipMemcpyAsync(xyzw + off * 4, dx, cnt * 16, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(rgba + off * 4, dc, cnt * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, sync_streams(c));
     }
     dfree(dx); dfree(dc);
     return launch_check(c, "soa_to_aos");
@@ -537,7 +655,7 @@ int rtr_set_resolution(rtr_ctx *c, int W, int H) {
     NEED(c, W > 0 && H > 0 && (int64_t)W * H < (1ll << 31), "bad resolution");
     if (W == c->W && H == c->H) return RTR_OK;
     DevGuard g(c->device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_streams(c));
     free_frame(c);
     size_t npix = (size_t)W * H;
     HIP_TRY(c, hipMalloc((void **)&c->depth, npix * 4));
@@ -569,26 +687,38 @@ static bool use_tiles(const rtr_ctx *c) {
 }
 
 // T1..T3 of the tile-binned form: stream + candidate lists + tile histogram, scan, scatter
-static int bin_points(rtr_ctx *c, const float P[16]) {
+// With `overlapped` T1 goes to the front stream and fills the set the tail is NOT reading, so it
+// runs beside T2..F5 of the previous frame (which are latency-bound and leave HBM idle).
+static int bin_points(rtr_ctx *c, const float P[16], bool overlapped = false) {
     c->list_valid = false;
+    hipStream_t s1 = c->stream;
+    if (overlapped) {
+        c->cur ^= 1;
+        s1 = c->front;
+        if (c->F().consumed_valid) HIP_TRY(c, hipStreamWaitEvent(c->front, c->F().consumed, 0));
+    }
     if (int rc = ensure_lists(c)) return rc;
-    if (int rc = ensure_tiles(c)) return rc;
+    if (int rc = ensure_tiles(c, s1)) return rc;
     {
-        size_t need = (size_t)(rtr::list_num_waves(c->n, c->opt_grid) / 4 + 1) * (size_t)c->tiles_n;
-        if (!c->bins.blk_hist || c->blk_hist_n != need) {
-            dfree(c->bins.blk_hist);
-            HIP_TRY(c, hipMalloc((void **)&c->bins.blk_hist, need * sizeof(uint32_t)));
-            c->blk_hist_n = need;
+        size_t need = (size_t)(rtr::list_num_waves(c->n, c->opt_grid) / 4 + 1) * (size_t)c->F().tiles_n;
+        if (!c->F().bins.blk_hist || c->F().blk_hist_n != need) {
+            dfree(c->F().bins.blk_hist);
+            HIP_TRY(c, hipMalloc((void **)&c->F().bins.blk_hist, need * sizeof(uint32_t)));
+            c->F().blk_hist_n = need;
         }
     }
     {
-        Timed t(c, RTR_K_MIN_DEPTH);
-        rtr::launch_project_bin(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->lists, c->bins.tile_hist,
-                                c->bins.blk_hist, c->opt_cull ? c->bounds : nullptr);
+        Timed t(c, RTR_K_MIN_DEPTH, s1);
+        rtr::launch_project_bin(s1, cloud_of(c), make_proj(P), c->W, c->H, c->F().lists, c->F().bins.tile_hist,
+                                c->F().bins.blk_hist, c->opt_cull ? c->bounds : nullptr);
+    }
+    if (overlapped) {
+        HIP_TRY(c, hipEventRecord(c->F().binned, c->front));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->F().binned, 0));
     }
     {
         Timed t(c, RTR_K_BIN);
-        rtr::launch_bin_sort(c->stream, cloud_of(c), c->W, c->H, c->lists, c->bins);
+        rtr::launch_bin_sort(c->stream, cloud_of(c), c->W, c->H, c->F().lists, c->F().bins);
     }
     memcpy(c->list_P, P, sizeof c->list_P);
     c->list_valid = true;
@@ -604,8 +734,9 @@ int rtr_min_depth_pass(rtr_ctx *c, const float P[16]) {
     if (use_tiles(c)) {
         if (int rc = bin_points(c, P)) return rc;
         Timed t(c, RTR_K_TILE);
-        rtr::launch_tile(c->stream, 1, cloud_of(c), c->W, c->H, c->bins, c->prm.depth_window, c->depth, c->acc, c->img,
+        rtr::launch_tile(c->stream, 1, cloud_of(c), c->W, c->H, c->F().bins, c->prm.depth_window, c->depth, c->acc, c->img,
                          0, nullptr);
+        mark_consumed(c);
     } else {
         Timed t(c, RTR_K_MIN_DEPTH);
         rtr::launch_min_depth(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->depth);
@@ -623,8 +754,9 @@ int rtr_accumulate_pass(rtr_ctx *c, const float P[16]) {
     const bool use_bins = use_tiles(c) && c->list_valid && memcmp(c->list_P, P, sizeof c->list_P) == 0;
     if (use_bins) {
         Timed t(c, RTR_K_TILE);
-        rtr::launch_tile(c->stream, 2, cloud_of(c), c->W, c->H, c->bins, c->prm.depth_window, c->depth, c->acc, c->img,
+        rtr::launch_tile(c->stream, 2, cloud_of(c), c->W, c->H, c->F().bins, c->prm.depth_window, c->depth, c->acc, c->img,
                          1, nullptr);
+        mark_consumed(c);
     } else {
         Timed t(c, RTR_K_ACCUMULATE);
         rtr::launch_accumulate(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->depth, c->acc, c->prm.depth_window);
@@ -694,7 +826,7 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
     }
     if (tiles) {  // one launch does clear + min + accumulate + resolve per tile
         DevGuard g(c->device);
-        if ((rc = bin_points(c, P))) return rc;
+        if ((rc = bin_points(c, P, c->opt_overlap && c->front))) return rc;
         // with the default four levels the tile kernel also emits the prefilter's pyramid and
         // min / max partials (F1) while the finished depth tile is still in LDS
         rtr::TilePyr pyr{};
@@ -707,9 +839,10 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
         }
         {
             Timed t(c, RTR_K_TILE);
-            rtr::launch_tile(c->stream, 0, cloud_of(c), c->W, c->H, c->bins, c->prm.depth_window, c->depth, c->acc,
+            rtr::launch_tile(c->stream, 0, cloud_of(c), c->W, c->H, c->F().bins, c->prm.depth_window, c->depth, c->acc,
                              c->img, c->opt_keep_accum, pyr.enable ? &pyr : nullptr);
         }
+        mark_consumed(c);
         if ((rc = launch_check(c, "tile frame"))) return rc;
         if (with_filter) return filter_impl(c, pyr.enable ? rtr::tile_count(c->W, c->H) : 0);
         return RTR_OK;
@@ -735,7 +868,7 @@ static int frame_to_host(rtr_ctx *c, const float P[16], uint8_t *host_img, float
     size_t npix = (size_t)c->W * c->H;
     if (host_depth) HIP_TRY(c, hipMemcpyAsync(host_depth, c->depth, npix * 4, hipMemcpyDeviceToHost, c->stream));
     if (host_img) HIP_TRY(c, hipMemcpyAsync(host_img, c->img, npix * 3, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_streams(c));
     return RTR_OK;
 }
 
@@ -779,7 +912,7 @@ int rtr_download_buffer(rtr_ctx *c, int which, void *host, size_t bytes) {
     NEED(c, bytes == b, "size mismatch");
     DevGuard g(c->device);
     HIP_TRY(c, hipMemcpyAsync(host, p, b, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_streams(c));
     return RTR_OK;
 }
 

@@ -735,7 +735,7 @@ __device__ __forceinline__ void tile_pyramid(const uint32_t *s_depth, uint32_t *
             a = s_mm[k] < a ? s_mm[k] : a;
             b = s_mm[nw + k] > b ? s_mm[nw + k] : b;
         }
-        part_min[tile] = a;
+        part_min[tile] = a;  // (same-address global atomics instead cost T4 25 us)
         part_max[tile] = b;
     }
     const int w2 = w1 >> 1, n2 = n1 >> 2;
@@ -823,7 +823,11 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__
                 d[k] = r.depth;
             }
 #pragma unroll
-            for (int k = 0; k < kTileBatch; ++k) atomicMin(&s_depth[t[k] & tmask], d[k]);  // render.cu:81
+            for (int k = 0; k < kTileBatch; ++k) {  // render.cu:81, behind an early-z read: an LDS read
+                // costs a fraction of an LDS atomic, and only a few entries per pixel lower its minimum
+                uint32_t *slot = &s_depth[t[k] & tmask];
+                if ((dbg & 256) || d[k] < *reinterpret_cast<volatile uint32_t *>(slot)) atomicMin(slot, d[k]);
+            }
         }
         __syncthreads();
     }
@@ -1167,44 +1171,72 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const float *__restrict__ hi,
     lo[idx] = min2(min2(a.x, a.y), min2(b.x, b.y));
 }
 
+// A pyramid level as the kernels below read it: in memory (row stride = its width) or as a
+// window of it staged in LDS.  w / h are the dims the reference's launch sequence uses for the
+// level (heights are the doubled TRUNCATED ones, project_cloud.cu:360-361).
+struct MemLevel {
+    const float *p; int w, h;
+    __device__ __forceinline__ float at(int x, int y) const { return p[(size_t)y * w + x]; }
+};
+struct LdsLevel {
+    const float *p; int ox, oy, sw;  // window origin and row stride
+    int w, h;
+    __device__ __forceinline__ float at(int x, int y) const { return p[(y - oy) * sw + (x - ox)]; }
+};
+
 // A9 laplacianKernel (project_cloud.cu:55-79) for ONE low-res pixel: border -> 0, else the
 // nine-tap fmaf chain in row-major order (zero-weight corners included) compared with thr.
-__device__ __forceinline__ bool lap_flag(const float *__restrict__ lo, int x, int y, int w, int h, float thr) {
-    if (x == 0 || x == w - 1 || y == 0 || y == h - 1) return false;
-    const float *r = lo + (size_t)(y - 1) * w + (x - 1);
+template <class Lv>
+__device__ __forceinline__ bool lap_flag(const Lv &lo, int x, int y, float thr) {
+    if (x == 0 || x == lo.w - 1 || y == 0 || y == lo.h - 1) return false;
     float sum = 0.0f;
-    sum = fmaf(r[0], 0.0f, sum);
-    sum = fmaf(r[1], 1.0f, sum);
-    sum = fmaf(r[2], 0.0f, sum);
-    r += w;
-    sum = fmaf(r[0], 1.0f, sum);
-    sum = fmaf(r[1], -4.0f, sum);
-    sum = fmaf(r[2], 1.0f, sum);
-    r += w;
-    sum = fmaf(r[0], 0.0f, sum);
-    sum = fmaf(r[1], 1.0f, sum);
-    sum = fmaf(r[2], 0.0f, sum);
+    sum = fmaf(lo.at(x - 1, y - 1), 0.0f, sum);
+    sum = fmaf(lo.at(x, y - 1), 1.0f, sum);
+    sum = fmaf(lo.at(x + 1, y - 1), 0.0f, sum);
+    sum = fmaf(lo.at(x - 1, y), 1.0f, sum);
+    sum = fmaf(lo.at(x, y), -4.0f, sum);
+    sum = fmaf(lo.at(x + 1, y), 1.0f, sum);
+    sum = fmaf(lo.at(x - 1, y + 1), 0.0f, sum);
+    sum = fmaf(lo.at(x, y + 1), 1.0f, sum);
+    sum = fmaf(lo.at(x + 1, y + 1), 0.0f, sum);
     return sum > thr;
 }
 
-__device__ __forceinline__ float lo_px(const float *__restrict__ lo, int x, int y, int w, int h) {
-    return (x >= 0 && x < w && y >= 0 && y < h) ? lo[(size_t)y * w + x] : -1.0f;  // project_cloud.cu:81-86
+template <class Lv>
+__device__ __forceinline__ float lo_px(const Lv &lo, int x, int y) {
+    return (x >= 0 && x < lo.w && y >= 0 && y < lo.h) ? lo.at(x, y) : -1.0f;  // project_cloud.cu:81-86
 }
 
 // A10 compareImgsKernel (project_cloud.cu:88-126) for one hi-res pixel
-__device__ __forceinline__ bool keep_px(const float *__restrict__ lo, float cur, int x, int y, int lw, int lh,
-                                        float strength, float thr) {
+template <class Lv>
+__device__ __forceinline__ bool keep_px(const Lv &lo, float cur, int x, int y, float strength, float thr) {
     if ((double)cur >= 3.4028e38) return false;  // MAX_FLOAT, project_cloud.cu:21,97
     const int lx = x >> 1, ly = y >> 1;
-    if (lap_flag(lo, lx, ly, lw, lh, thr)) {
+    if (lap_flag(lo, lx, ly, thr)) {
         bool keep = false;
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) keep = keep || (cur <= f_mul(lo_px(lo, lx + dx, ly + dy, lw, lh), strength));
+            for (int dx = -1; dx <= 1; ++dx) keep = keep || (cur <= f_mul(lo_px(lo, lx + dx, ly + dy), strength));
         return keep;
     }
-    return cur <= f_mul(lo_px(lo, lx, ly, lw, lh), strength);
+    return cur <= f_mul(lo_px(lo, lx, ly), strength);
+}
+
+// A11 resize (project_cloud.cu:128-161): bilinear x2 up-sample of lo at hi-res pixel (x, y)
+template <class Lv>
+__device__ __forceinline__ float bilerp(const Lv &lo, int x, int y) {
+    float inX = f_sub(f_add((float)x, 0.5f) / 2.0f, 0.5f);
+    float inY = f_sub(f_add((float)y, 0.5f) / 2.0f, 0.5f);
+    int x0 = (int)floorf(inX), x1 = x0 + 1, y0 = (int)floorf(inY), y1 = y0 + 1;
+    x0 = x0 < 0 ? 0 : (x0 >= lo.w ? lo.w - 1 : x0);
+    x1 = x1 < 0 ? 0 : (x1 >= lo.w ? lo.w - 1 : x1);
+    y0 = y0 < 0 ? 0 : (y0 >= lo.h ? lo.h - 1 : y0);
+    y1 = y1 < 0 ? 0 : (y1 >= lo.h ? lo.h - 1 : y1);
+    float wx = f_sub(inX, (float)x0), wy = f_sub(inY, (float)y0);
+    float v0 = fmaf(wx, lo.at(x1, y0), f_mul(f_sub(1.0f, wx), lo.at(x0, y0)));
+    float v1 = fmaf(wx, lo.at(x1, y1), f_mul(f_sub(1.0f, wx), lo.at(x0, y1)));
+    return fmaf(wy, v1, f_mul(f_sub(1.0f, wy), v0));
 }
 
 // F2..F4: level i (lo, lw x lh) against level i-1 (hi, 2lw x 2lh): compare, and where the
@@ -1249,18 +1281,9 @@ __global__ __launch_bounds__(kBlock) void k_up(const float *__restrict__ lo, flo
     int idx = blockIdx.x * kBlock + threadIdx.x;
     if (idx >= ow * oh) return;
     int x = idx % ow, y = idx / ow;
-    if (keep_px(lo, hi[idx], x, y, lw, lh, strength, thr)) return;
-    float inX = f_sub(f_add((float)x, 0.5f) / 2.0f, 0.5f);
-    float inY = f_sub(f_add((float)y, 0.5f) / 2.0f, 0.5f);
-    int x0 = (int)floorf(inX), x1 = x0 + 1, y0 = (int)floorf(inY), y1 = y0 + 1;
-    x0 = x0 < 0 ? 0 : (x0 >= lw ? lw - 1 : x0);
-    x1 = x1 < 0 ? 0 : (x1 >= lw ? lw - 1 : x1);
-    y0 = y0 < 0 ? 0 : (y0 >= lh ? lh - 1 : y0);
-    y1 = y1 < 0 ? 0 : (y1 >= lh ? lh - 1 : y1);
-    float wx = f_sub(inX, (float)x0), wy = f_sub(inY, (float)y0);
-    float v0 = fmaf(wx, lo[(size_t)y0 * lw + x1], f_mul(f_sub(1.0f, wx), lo[(size_t)y0 * lw + x0]));
-    float v1 = fmaf(wx, lo[(size_t)y1 * lw + x1], f_mul(f_sub(1.0f, wx), lo[(size_t)y1 * lw + x0]));
-    hi[idx] = fmaf(wy, v1, f_mul(f_sub(1.0f, wy), v0));
+    const MemLevel lv{lo, lw, lh};
+    if (keep_px(lv, hi[idx], x, y, strength, thr)) return;
+    hi[idx] = bilerp(lv, x, y);
 }
 
 __device__ __forceinline__ uint32_t to_half_bits(float f) {
@@ -1269,28 +1292,22 @@ __device__ __forceinline__ uint32_t to_half_bits(float f) {
 }
 __device__ __forceinline__ float half_round(float f) { return __half2float(__float2half_rn(f)); }
 
-// F5: level-0 compare (A10) + removeMask (A13, project_cloud.cu:163-187) over ALL W*H
-// pixels, four horizontally adjacent pixels per thread (W % 16 == 0), tensor plane stride
-// W*H (the reference strides by W*H_eff: quirk Q3).  Rows >= H_eff never saw the pyramid
-// test: their mask is "non-empty".
-__global__ __launch_bounds__(kBlock) void k_final(const float *__restrict__ l1, float *__restrict__ depth,
-                                                  uint8_t *__restrict__ img, uint8_t *__restrict__ mask,
-                                                  uint16_t *__restrict__ tensor, const uint32_t *__restrict__ minmax,
-                                                  int W, int H, int lw, int lh, float strength, float thr) {
-    const size_t npix = (size_t)W * H, q = (size_t)blockIdx.x * kBlock + threadIdx.x, idx = q * 4;
-    if (idx >= npix) return;
-    const int x = (int)(idx % W), y = (int)(idx / W);
-    const float mn = __uint_as_float(minmax[0]), range = f_sub(__uint_as_float(minmax[1]), mn);
-    float4 d4 = *reinterpret_cast<float4 *>(depth + idx);
+// Level-0 compare (A10) + removeMask (A13, project_cloud.cu:163-187) for four horizontally
+// adjacent pixels (W % 16 == 0), tensor plane stride W*H (the reference strides by W*H_eff:
+// quirk Q3).  Rows >= H_eff never saw the pyramid test: their mask is "non-empty".
+template <class Lv>
+__device__ __forceinline__ void final_quad(const Lv &l1, float4 d4, uint32_t iw0, uint32_t iw1, uint32_t iw2,
+                                           float *__restrict__ depth, uint8_t *__restrict__ img,
+                                           uint8_t *__restrict__ mask, uint16_t *__restrict__ tensor, float mn,
+                                           float range, int x, int y, size_t idx, size_t npix, bool in_domain,
+                                           float strength, float thr) {
     float d[4] = {d4.x, d4.y, d4.z, d4.w};
-    uint32_t *ip = reinterpret_cast<uint32_t *>(img + idx * 3);
-    uint32_t iw[3] = {ip[0], ip[1], ip[2]};
+    uint32_t iw[3] = {iw0, iw1, iw2};
     uint32_t mbits = 0;
     uint32_t th[5][4];
-    const bool in_domain = y < 2 * lh;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        bool keep = in_domain ? keep_px(l1, d[k], x + k, y, lw, lh, strength, thr) : !((double)d[k] >= 3.4028e38);
+        bool keep = in_domain ? keep_px(l1, d[k], x + k, y, strength, thr) : !((double)d[k] >= 3.4028e38);
         if (!keep) {
             d[k] = -1.0f;
             th[0][k] = th[1][k] = th[2][k] = th[3][k] = 0;
@@ -1318,6 +1335,7 @@ __global__ __launch_bounds__(kBlock) void k_final(const float *__restrict__ l1, 
             }
         }
     *reinterpret_cast<float4 *>(depth + idx) = make_float4(d[0], d[1], d[2], d[3]);
+    uint32_t *ip = reinterpret_cast<uint32_t *>(img + idx * 3);
     ip[0] = iw[0];
     ip[1] = iw[1];
     ip[2] = iw[2];
@@ -1326,6 +1344,122 @@ __global__ __launch_bounds__(kBlock) void k_final(const float *__restrict__ l1, 
     for (int c = 0; c < 5; ++c)
         *reinterpret_cast<uint2 *>(tensor + (size_t)c * npix + idx) =
             make_uint2(th[c][0] | (th[c][1] << 16), th[c][2] | (th[c][3] << 16));
+}
+
+// F5 of the generic sequence: final_quad over ALL W*H pixels, level 1 read from memory
+__global__ __launch_bounds__(kBlock) void k_final(const float *__restrict__ l1, float *__restrict__ depth,
+                                                  uint8_t *__restrict__ img, uint8_t *__restrict__ mask,
+                                                  uint16_t *__restrict__ tensor, const uint32_t *__restrict__ minmax,
+                                                  int W, int H, int lw, int lh, float strength, float thr) {
+    const size_t npix = (size_t)W * H, q = (size_t)blockIdx.x * kBlock + threadIdx.x, idx = q * 4;
+    if (idx >= npix) return;
+    const int x = (int)(idx % W), y = (int)(idx / W);
+    const float mn = __uint_as_float(minmax[0]), range = f_sub(__uint_as_float(minmax[1]), mn);
+    const float4 d4 = *reinterpret_cast<float4 *>(depth + idx);
+    const uint32_t *ip = reinterpret_cast<const uint32_t *>(img + idx * 3);
+    final_quad(MemLevel{l1, lw, lh}, d4, ip[0], ip[1], ip[2], depth, img, mask, tensor, mn, range, x, y, idx, npix,
+               y < 2 * lh, strength, thr);
+}
+
+// The whole prefilter after the pyramid in ONE launch (default four levels): a workgroup owns a
+// 64x16 block of the frame and recomputes, in LDS, the part of every level its block depends on.
+// k_up(i) only reads level i (final) and rewrites single pixels of level i-1, and a level i-1
+// pixel depends on the 3x3 neighbourhood of its parent, so the block needs level 1 on a 34x10
+// window, level 2 on 20x8, level 3 on 12x6 and the untouched level 4 on 8x5: ~0.5 % more
+// arithmetic instead of three dependent launches and their round trips (the k_up / k_final
+// sequence costs 31 us alone and 170 us beside a streaming kernel; the pyramid levels are
+// not written back, nothing reads them after the prefilter).
+// Window of level i for the 64x16 block at (X0, Y0): origin X0 / 2^i - 1 (level 1) or - 2 (levels
+// 2..4), same in y; the extents follow from "parents of the window plus their 3x3 neighbours",
+// [(a >> 1) - 1, ((b - 1) >> 1) + 2) for a child window [a, b): 34x10, 20x8, 12x6, 8x5.
+// (64 wide so that a wave's stores are whole 128 B lines in every output plane.)
+constexpr int kFuseW = 64, kFuseH = 16;
+constexpr int kF1x = 34, kF1y = 10, kF2x = 20, kF2y = 8, kF3x = 12, kF3y = 6, kF4x = 8, kF4y = 5;
+
+template <int SX, int SY>
+__device__ __forceinline__ void stage_level(float *dst, int ox, int oy, const float *__restrict__ src, int lw, int lh) {
+    for (int q = threadIdx.x; q < SX * SY; q += kBlock) {
+        const int gx = ox + q % SX, gy = oy + q / SX;
+        dst[q] = (gx >= 0 && gx < lw && gy >= 0 && gy < lh) ? src[(size_t)gy * lw + gx] : 0.0f;
+    }
+}
+template <int SX, int SY>
+__device__ __forceinline__ void up_level(float *hi, int ox, int oy, int hw, int hh, const LdsLevel &lo, float strength,
+                                         float thr) {
+    for (int q = threadIdx.x; q < SX * SY; q += kBlock) {
+        const int gx = ox + q % SX, gy = oy + q / SX;
+        if (gx < 0 || gx >= hw || gy < 0 || gy >= hh) continue;
+        if (!keep_px(lo, hi[q], gx, gy, strength, thr)) hi[q] = bilerp(lo, gx, gy);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_filter4(const float *__restrict__ g1, const float *__restrict__ g2,
+                                                    const float *__restrict__ g3, const float *__restrict__ g4,
+                                                    int h4, float *__restrict__ depth, uint8_t *__restrict__ img,
+                                                    uint8_t *__restrict__ mask, uint16_t *__restrict__ tensor,
+                                                    const uint32_t *__restrict__ part_min,
+                                                    const uint32_t *__restrict__ part_max, int nparts,
+                                                    uint32_t *__restrict__ minmax, int W, int H, int blocks_x,
+                                                    float strength, float thr) {
+    __shared__ float s1[kF1x * kF1y], s2[kF2x * kF2y], s3[kF3x * kF3y], s4[kF4x * kF4y];
+    __shared__ uint32_t s_mm[8];
+    const int X0 = (blockIdx.x % blocks_x) * kFuseW, Y0 = (blockIdx.x / blocks_x) * kFuseH;
+    const int t = threadIdx.x, x = X0 + 4 * (t & 15), y = Y0 + (t >> 4);
+    const bool inb = x < W && y < H;
+    const size_t npix = (size_t)W * H, idx = (size_t)y * W + x;
+    // the frame-sized loads go first: everything below overlaps their round trip
+    float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t iw0 = 0, iw1 = 0, iw2 = 0;
+    if (inb) {
+        d4 = *reinterpret_cast<const float4 *>(depth + idx);
+        const uint32_t *ip = reinterpret_cast<const uint32_t *>(img + idx * 3);
+        iw0 = ip[0]; iw1 = ip[1]; iw2 = ip[2];
+    }
+    // A12: every workgroup folds the per-tile min / max partials itself (a few KB out of L2, in
+    // the shadow of the loads above) rather than waiting for a fold launch
+    uint32_t fa = 0xFFFFFFFFu, fb = 0u;
+    for (int k = t; k < nparts; k += kBlock) {
+        const uint32_t pa = part_min[k], pb = part_max[k];
+        fa = pa < fa ? pa : fa;
+        fb = pb > fb ? pb : fb;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t oa = __shfl_xor(fa, off, 64), ob = __shfl_xor(fb, off, 64);
+        fa = oa < fa ? oa : fa;
+        fb = ob > fb ? ob : fb;
+    }
+    if ((t & 63) == 0) {
+        s_mm[t >> 6] = fa;
+        s_mm[4 + (t >> 6)] = fb;
+    }
+    const int w1 = W >> 1, w2 = W >> 2, w3 = W >> 3, w4 = W >> 4, h3 = 2 * h4, h2 = 4 * h4, h1 = 8 * h4;
+    const int x1 = (X0 >> 1) - 1, y1 = (Y0 >> 1) - 1, x2 = (X0 >> 2) - 2, y2 = (Y0 >> 2) - 2;
+    const int x3 = (X0 >> 3) - 2, y3 = (Y0 >> 3) - 2, x4 = (X0 >> 4) - 2, y4 = (Y0 >> 4) - 2;
+    stage_level<kF1x, kF1y>(s1, x1, y1, g1, w1, h1);
+    stage_level<kF2x, kF2y>(s2, x2, y2, g2, w2, h2);
+    stage_level<kF3x, kF3y>(s3, x3, y3, g3, w3, h3);
+    stage_level<kF4x, kF4y>(s4, x4, y4, g4, w4, h4);
+    __syncthreads();
+    up_level<kF3x, kF3y>(s3, x3, y3, w3, h3, LdsLevel{s4, x4, y4, kF4x, w4, h4}, strength, thr);
+    __syncthreads();
+    up_level<kF2x, kF2y>(s2, x2, y2, w2, h2, LdsLevel{s3, x3, y3, kF3x, w3, h3}, strength, thr);
+    __syncthreads();
+    up_level<kF1x, kF1y>(s1, x1, y1, w1, h1, LdsLevel{s2, x2, y2, kF2x, w2, h2}, strength, thr);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        fa = s_mm[k] < fa ? s_mm[k] : fa;
+        fb = s_mm[4 + k] > fb ? s_mm[4 + k] : fb;
+    }
+    if (blockIdx.x == 0 && t == 0) {
+        minmax[0] = fa;
+        minmax[1] = fb;
+    }
+    const float mn = __uint_as_float(fa), range = f_sub(__uint_as_float(fb), mn);
+    if (!inb) return;
+    final_quad(LdsLevel{s1, x1, y1, kF1x, w1, h1}, d4, iw0, iw1, iw2, depth, img, mask, tensor, mn, range,
+               x, y, idx, npix, y < 2 * h1, strength, thr);
 }
 
 // A14 applyDepthFilter (project_cloud.cu:331-392)
@@ -1337,9 +1471,16 @@ void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, u
     const int h_eff = (H >> nl) << nl;
     const int tiles_x = (W + 31) / 32, tiles_y = (H + 31) / 32;
     int nparts = tiles_x * tiles_y;
-    if (pyramid_parts > 0) {  // T4 already produced levels 1..4 and the per-tile partials
-        nparts = pyramid_parts;
-    } else {
+    if (nl == 4) {  // default: everything after the pyramid in one launch
+        if (pyramid_parts == 0)  // phase call: T4 did not produce the levels and the min / max partials
+            hipLaunchKernelGGL(k_pyramid, dim3(nparts), dim3(kBlock), 0, s, L, tiles_x, (uint32_t)h_eff, part_min, part_max);
+        const int bx = (W + kFuseW - 1) / kFuseW, by = (H + kFuseH - 1) / kFuseH;
+        hipLaunchKernelGGL(k_filter4, dim3(bx * by), dim3(kBlock), 0, s, L.lv[1], L.lv[2], L.lv[3], L.lv[4], L.h[4],
+                           (float *)depth_bits, img, mask, tensor, part_min, part_max,
+                           pyramid_parts > 0 ? pyramid_parts : nparts, minmax, W, H, bx, strength, thr);
+        return;
+    }
+    {
         FilterLevels L4 = L;
         if (L4.levels > 4) L4.levels = 4;
         hipLaunchKernelGGL(k_pyramid, dim3(nparts), dim3(kBlock), 0, s, L4, tiles_x, (uint32_t)h_eff, part_min, part_max);

@@ -392,3 +392,58 @@ def test_hot_tile_fallback_sequence(pkg, orc, projector):
         ref = refs[id(P)]
         assert np.array_equal(depth.view(np.uint32), ref["depth_bits"]), k
         assert np.array_equal(img, ref["img"]), k
+
+
+@pytest.mark.parametrize("tail_cus", [0, 8])
+def test_overlap_option_keeps_every_frame(pkg, orc, projector, tail_cus):
+    """Option "overlap": T1 of a whole-frame render runs on a second stream and fills the list /
+    bin set the tail of the previous frame is not reading (optionally with disjoint CU masks).
+    Frames queued back to back without synchronisation, mixed with phase calls and a new cloud,
+    stay bit-identical to the oracle."""
+    W, H = 640, 480
+    xyzw, rgba = orc.generate("room_shell", 77, 0, 300_000, 300_000)
+    poses = [pkg.orbit_projection(k, W, H) for k in range(12)]
+    projector.upload_points(xyzw, rgba)
+    projector.set_resolution(W, H)
+    projector.set_option("tail_cus", tail_cus)
+    try:
+        projector.set_option("overlap", 1)
+    except pkg.RtrError:
+        if tail_cus:
+            pytest.skip("CU-masked streams are not available on this device")
+        raise
+    try:
+        def check(P, cloud_xyzw, cloud_rgba):
+            ref = orc.project(cloud_xyzw, cloud_rgba, P, W, H)
+            rf = orc.filter(ref["depth_bits"], ref["img"])
+            assert np.array_equal(projector.download(pkg._lib.BUF_TENSOR).reshape(5, H, W), rf["tensor"])
+            assert np.array_equal(projector.download(pkg._lib.BUF_MASK), rf["mask"])
+            assert np.array_equal(projector.download(pkg._lib.BUF_MINMAX), rf["minmax"])
+
+        for k in range(7):          # 7 frames in flight, no synchronisation in between
+            projector.render(poses[k], True)
+        check(poses[6], xyzw, rgba)
+        projector.render(poses[7], True)
+        projector.clear()           # phase calls use the active set on the tail stream
+        projector.min_depth_pass(poses[8])
+        projector.accumulate_pass(poses[8])
+        projector.resolve()
+        projector.filter()
+        check(poses[8], xyzw, rgba)
+        projector.render(poses[9], True)
+        projector.render(poses[10], True)
+        check(poses[10], xyzw, rgba)
+        xyzw2, rgba2 = orc.generate("uniform_box", 78, 0, 200_000, 200_000)
+        projector.render(poses[11], True)
+        projector.upload_points(xyzw2, rgba2)   # must wait for the front stream too
+        projector.render(poses[3], True)
+        projector.render(poses[4], True)
+        check(poses[4], xyzw2, rgba2)
+        img, depth = projector.project(poses[5], filtered=True)
+        ref = orc.project(xyzw2, rgba2, poses[5], W, H)
+        rf = orc.filter(ref["depth_bits"], ref["img"])
+        assert np.array_equal(img, rf["img"])
+        assert np.array_equal(depth.view(np.uint32), rf["depth"].view(np.uint32))
+    finally:
+        projector.set_option("overlap", 0)
+        projector.set_option("tail_cus", 0)
