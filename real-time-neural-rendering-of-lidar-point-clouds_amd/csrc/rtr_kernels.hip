@@ -563,39 +563,49 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
 __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *__restrict__ tile_hist, uint32_t *__restrict__ tile_start,
                                                     uint32_t *__restrict__ cursor, uint32_t *__restrict__ order,
                                                     uint32_t *__restrict__ stats, int ntiles) {
-    __shared__ uint32_t s_part[1024];
+    __shared__ uint32_t s_w[16], s_m[16];
     const int per = (ntiles + 1023) / 1024;  // <= 4 (ntiles <= 4096)
     const int lo = threadIdx.x * per;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t cnt[4] = {0, 0, 0, 0}, sum = 0;
     for (int k = 0; k < per && k < 4; ++k)
         if (lo + k < ntiles) {
             cnt[k] = tile_hist[lo + k];
             sum += cnt[k];
         }
-    auto scan = [&](uint32_t mine) {  // Hillis-Steele inclusive scan over the workgroup
-        s_part[threadIdx.x] = mine;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            uint32_t v = (threadIdx.x >= (unsigned)off) ? s_part[threadIdx.x - off] : 0u;
-            __syncthreads();
-            s_part[threadIdx.x] += v;
-            __syncthreads();
+    // inclusive scan over the workgroup (16 waves): shuffles inside a wave, one LDS hop across
+    // waves; `mx` rides along as a workgroup max.  Three barriers instead of the ~20 of a
+    // Hillis-Steele scan through LDS -- this kernel is pure latency on the frame's critical path.
+    auto scan = [&](uint32_t v, uint32_t &total, uint32_t &mx) -> uint32_t {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(v, off, 64);
+            if (lane >= off) v += o;
         }
-    };
-    auto scan_max = [&](uint32_t mine) {  // workgroup max, result in s_part[0]
-        s_part[threadIdx.x] = mine;
-        __syncthreads();
-        for (int off = 512; off > 0; off >>= 1) {
-            if (threadIdx.x < (unsigned)off) {
-                uint32_t o = s_part[threadIdx.x + off];
-                if (o > s_part[threadIdx.x]) s_part[threadIdx.x] = o;
-            }
-            __syncthreads();
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = __shfl_xor(mx, off, 64);
+            mx = o > mx ? o : mx;
         }
+        if (lane == 63) s_w[wv] = v;
+        if (lane == 0) s_m[wv] = mx;
+        __syncthreads();
+        uint32_t base = 0;
+        total = 0;
+        mx = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {  // broadcast reads
+            const uint32_t wsum = s_w[k];
+            base += k < wv ? wsum : 0u;
+            total += wsum;
+            mx = s_m[k] > mx ? s_m[k] : mx;
+        }
+        __syncthreads();  // s_w / s_m are reused by the next scan
+        return v + base;
     };
-    scan(sum);
-    const uint32_t total = s_part[1023];
-    uint32_t run = s_part[threadIdx.x] - sum;  // exclusive prefix of this thread's chunk
+    uint32_t total = 0, mx = 0;
+    for (int k = 0; k < per && k < 4; ++k) mx = cnt[k] > mx ? cnt[k] : mx;
+    uint32_t run = scan(sum, total, mx) - sum;  // exclusive prefix of this thread's chunk
     for (int k = 0; k < per && k < 4; ++k)
         if (lo + k < ntiles) {
             tile_start[lo + k] = run;
@@ -604,27 +614,19 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *__restrict__ tile_
             run += cnt[k];
         }
     if (threadIdx.x == 1023) tile_start[ntiles] = total;
-    __syncthreads();
     // frame statistics for the host (mapped host memory, read without synchronisation): total
     // entries and the entry count of the heaviest tile (one workgroup owns a whole tile in T4)
-    {
-        uint32_t mx = 0;
-        for (int k = 0; k < per && k < 4; ++k) mx = cnt[k] > mx ? cnt[k] : mx;
-        scan_max(mx);
-        if (threadIdx.x == 0 && stats) {
-            stats[0] = total;
-            stats[1] = s_part[0];
-        }
-        __syncthreads();
+    if (threadIdx.x == 0 && stats) {
+        stats[0] = total;
+        stats[1] = mx;
     }
     // launch order of the tile kernel: tiles with more than twice the mean entry count first,
     // so the few heavy tiles that bound T4 start at once instead of trailing the launch
     const uint32_t thr = 2u * (total / (uint32_t)ntiles) + 1u;
     uint32_t heavy = 0;
     for (int k = 0; k < per && k < 4; ++k) heavy += (lo + k < ntiles && cnt[k] > thr) ? 1u : 0u;
-    scan(heavy);
-    const uint32_t n_heavy = s_part[1023];
-    uint32_t h_before = s_part[threadIdx.x] - heavy;
+    uint32_t n_heavy = 0, unused = 0;
+    uint32_t h_before = scan(heavy, n_heavy, unused) - heavy;
     for (int k = 0; k < per && k < 4; ++k)
         if (lo + k < ntiles) {
             const bool h = cnt[k] > thr;
@@ -1223,6 +1225,54 @@ __device__ __forceinline__ bool keep_px(const Lv &lo, float cur, int x, int y, f
     return cur <= f_mul(lo_px(lo, lx, ly), strength);
 }
 
+// keep_px for four horizontally adjacent pixels x..x+3 (x % 4 == 0) of one row: they have two
+// parents, whose 3x3 neighbourhoods share a 4x3 window of the lower level, so the twelve taps
+// (and their products with `strength`) are fetched once and everything is branch-free.
+// Bit k of the result = keep_px(lo, d[k], x + k, y, ...).
+template <class Lv>
+__device__ __forceinline__ uint32_t keep_quad(const Lv &lo, const float d[4], int x, int y, float strength, float thr) {
+    const int lx = x >> 1, ly = y >> 1;
+    float v[3][4], p[3][4];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[j][i] = lo_px(lo, lx - 1 + i, ly - 1 + j);
+            p[j][i] = f_mul(v[j][i], strength);
+        }
+    uint32_t bits = 0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int X = lx + a;
+        bool flag = false;
+        if (!(X == 0 || X == lo.w - 1 || ly == 0 || ly == lo.h - 1)) {  // A9: the nine taps are in range here
+            float sum = 0.0f;
+            sum = fmaf(v[0][a], 0.0f, sum);
+            sum = fmaf(v[0][a + 1], 1.0f, sum);
+            sum = fmaf(v[0][a + 2], 0.0f, sum);
+            sum = fmaf(v[1][a], 1.0f, sum);
+            sum = fmaf(v[1][a + 1], -4.0f, sum);
+            sum = fmaf(v[1][a + 2], 1.0f, sum);
+            sum = fmaf(v[2][a], 0.0f, sum);
+            sum = fmaf(v[2][a + 1], 1.0f, sum);
+            sum = fmaf(v[2][a + 2], 0.0f, sum);
+            flag = sum > thr;
+        }
+#pragma unroll
+        for (int k = 2 * a; k < 2 * a + 2; ++k) {
+            const float cur = d[k];
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int i = a; i < a + 3; ++i) any = any | (cur <= p[j][i]);
+            const bool keep = !((double)cur >= 3.4028e38) & (flag ? any : (cur <= p[1][a + 1]));
+            bits |= keep ? (1u << k) : 0u;
+        }
+    }
+    return bits;
+}
+
 // A11 resize (project_cloud.cu:128-161): bilinear x2 up-sample of lo at hi-res pixel (x, y)
 template <class Lv>
 __device__ __forceinline__ float bilerp(const Lv &lo, int x, int y) {
@@ -1291,6 +1341,8 @@ __device__ __forceinline__ uint32_t to_half_bits(float f) {
     return __half_as_ushort(__float2half_rn(f));
 }
 __device__ __forceinline__ float half_round(float f) { return __half2float(__float2half_rn(f)); }
+// colour plane value of byte b: half(float(half(b)) / 255.0f) (A13); 256 possible results
+__device__ __forceinline__ uint32_t colour_half(uint32_t b) { return to_half_bits(half_round((float)b) / 255.0f); }
 
 // Level-0 compare (A10) + removeMask (A13, project_cloud.cu:163-187) for four horizontally
 // adjacent pixels (W % 16 == 0), tensor plane stride W*H (the reference strides by W*H_eff:
@@ -1300,14 +1352,21 @@ __device__ __forceinline__ void final_quad(const Lv &l1, float4 d4, uint32_t iw0
                                            float *__restrict__ depth, uint8_t *__restrict__ img,
                                            uint8_t *__restrict__ mask, uint16_t *__restrict__ tensor, float mn,
                                            float range, int x, int y, size_t idx, size_t npix, bool in_domain,
-                                           float strength, float thr) {
+                                           float strength, float thr, const uint16_t *lut = nullptr) {
     float d[4] = {d4.x, d4.y, d4.z, d4.w};
     uint32_t iw[3] = {iw0, iw1, iw2};
     uint32_t mbits = 0;
     uint32_t th[5][4];
+    uint32_t kbits = 0;
+    if (in_domain) {
+        kbits = keep_quad(l1, d, x, y, strength, thr);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) kbits |= !((double)d[k] >= 3.4028e38) ? (1u << k) : 0u;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        bool keep = in_domain ? keep_px(l1, d[k], x + k, y, strength, thr) : !((double)d[k] >= 3.4028e38);
+        const bool keep = (kbits >> k) & 1u;
         if (!keep) {
             d[k] = -1.0f;
             th[0][k] = th[1][k] = th[2][k] = th[3][k] = 0;
@@ -1317,8 +1376,8 @@ __device__ __forceinline__ void final_quad(const Lv &l1, float4 d4, uint32_t iw0
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 int byte = 3 * k + c;
-                float v = (float)((iw[byte >> 2] >> (8 * (byte & 3))) & 0xFFu);
-                th[c][k] = to_half_bits(half_round(v) / 255.0f);
+                const uint32_t b = (iw[byte >> 2] >> (8 * (byte & 3))) & 0xFFu;
+                th[c][k] = lut ? lut[b] : colour_half(b);
             }
             th[3][k] = 0x3C00u;  // half(float(half(255)) / 255.0f)
             th[4][k] = to_half_bits(half_round(f_sub(d[k], mn)) / range);
@@ -1403,6 +1462,9 @@ __global__ __launch_bounds__(kBlock) void k_filter4(const float *__restrict__ g1
                                                     float strength, float thr) {
     __shared__ float s1[kF1x * kF1y], s2[kF2x * kF2y], s3[kF3x * kF3y], s4[kF4x * kF4y];
     __shared__ uint32_t s_mm[8];
+    __shared__ uint16_t s_lut[256];  // colour byte -> fp16 bits: one IEEE division per thread instead of twelve
+    static_assert(kBlock == 256, "one table entry per thread");
+    s_lut[threadIdx.x] = (uint16_t)colour_half(threadIdx.x);
     const int X0 = (blockIdx.x % blocks_x) * kFuseW, Y0 = (blockIdx.x / blocks_x) * kFuseH;
     const int t = threadIdx.x, x = X0 + 4 * (t & 15), y = Y0 + (t >> 4);
     const bool inb = x < W && y < H;
@@ -1459,7 +1521,7 @@ __global__ __launch_bounds__(kBlock) void k_filter4(const float *__restrict__ g1
     const float mn = __uint_as_float(fa), range = f_sub(__uint_as_float(fb), mn);
     if (!inb) return;
     final_quad(LdsLevel{s1, x1, y1, kF1x, w1, h1}, d4, iw0, iw1, iw2, depth, img, mask, tensor, mn, range,
-               x, y, idx, npix, y < 2 * h1, strength, thr);
+               x, y, idx, npix, y < 2 * h1, strength, thr, s_lut);
 }
 
 // A14 applyDepthFilter (project_cloud.cu:331-392)
