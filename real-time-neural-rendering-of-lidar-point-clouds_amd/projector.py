@@ -205,14 +205,31 @@ class ProjectCloud:
 
     ctor: the reference flattens its grid into float4 / uchar4 arrays
     (project_cloud.cu:191-192, Octreegrid.h:162-180); here the caller passes those
-    flattened arrays (or tight xyz / rgb) directly.  `modelFilename` is accepted for
-    signature compatibility; the libtorch U-Net consumer stays outside this library and
-    reads the device tensor via `tensor_device_buffer()` (project_cloud.cu:471)."""
+    flattened arrays (or tight xyz / rgb) directly.  `modelFilename` names a TorchScript file
+    under $HOME/.render_cache like in the reference (project_cloud.cu:225-246); the U-Net itself
+    is not part of this library -- computeFull only hands it the device tensor (zero copy) and
+    post-processes its output (project_cloud.cu:471-487).  `set_model` accepts any callable
+    instead of a file."""
 
     def __init__(self, vertices, colors, modelFilename="", device=0):
+        self.modelFilename = modelFilename
+        self.model = None
+        self._device = device
+        self._bound_stream = None
+        if modelFilename != "":
+            import os
+            import torch
+            path = os.path.join(os.environ.get("HOME", ""), ".render_cache", modelFilename)
+            if not os.path.exists(path):  # the reference prints this and exits (project_cloud.cu:232-236)
+                raise FileNotFoundError("Model file does not exist: %s (export a TorchScript model for this "
+                                        "camera resolution first)" % path)
+            self.model = torch.jit.load(path, map_location="cuda:%d" % device)
         self._p = Projector(device)
         self._p.upload_points(vertices, colors)
-        self.modelFilename = modelFilename
+
+    def set_model(self, model):
+        """Use `model` (a callable taking the fp16 {1,5,H,W} cuda tensor) in computeFull."""
+        self.model = model
 
     @classmethod
     def from_grid(cls, grid, modelFilename="", device=0):
@@ -244,6 +261,38 @@ class ProjectCloud:
     def computeFilteredRGBD(self, calibration, extrinsics, color, depth):
         """project_cloud.cu:394-434."""
         return self._frame(calibration, extrinsics, color, depth, True)
+
+    def computeFull(self, calibration, extrinsics, color, depth):
+        """project_cloud.cu:437-493: projection + prefilter, then the model on the resident fp16
+        tensor; color <- uint8(round(output * 255)) like cv::Mat::convertTo(CV_8UC3, 255.0),
+        depth <- the prefiltered depth buffer.  Either output may be None; returns 1."""
+        import torch
+        if self.model is None:  # the reference warns in the ctor and then crashes in forward()
+            raise L.RtrError(L.RTR_ERR_INVALID, "No model: computeFull needs modelFilename or set_model()")
+        W, H = calibration.getWidth(), calibration.getHeight()
+        for name, arr, shape, dt in (("color", color, (H, W, 3), np.uint8), ("depth", depth, (H, W), np.float32)):
+            if arr is not None and (arr.dtype != dt or arr.shape != shape or not arr.flags.c_contiguous):
+                raise ValueError("%s must be a C-contiguous %s array of shape %s (main.cpp:93-94)" % (name, dt, shape))
+        dev = torch.device("cuda", self._device)
+        with torch.cuda.device(dev):
+            # kernels and the model share torch's current stream, so the hand-off needs no sync
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if self._bound_stream != stream:
+                self._p.set_stream(stream)
+                self._bound_stream = stream
+            self._p.set_resolution(W, H)
+            P = compose_projection(calibration.getIntrinsicsMatrix(), extrinsics)
+            self._p.render(P, True)
+            inp = torch.as_tensor(self._p.device_buffer(L.BUF_TENSOR), device=dev)  # zero copy (from_blob, :471)
+            with torch.no_grad():
+                out = self.model(inp)
+            out = out[0].permute(1, 2, 0).contiguous()  # :475
+            if color is not None:
+                img = (out.float() * 255.0).round().clamp(0, 255).to(torch.uint8)  # convertTo(CV_8UC3, 255.0), :480
+                color[...] = img.cpu().numpy()
+            if depth is not None:
+                depth[...] = self._p.download(L.BUF_DEPTH).view(np.float32)  # :485
+        return 1
 
     def tensor_device_buffer(self):
         """The planar fp16 {1,5,H,W} device tensor computeFull feeds to the U-Net

@@ -447,3 +447,52 @@ def test_overlap_option_keeps_every_frame(pkg, orc, projector, tail_cus):
     finally:
         projector.set_option("overlap", 0)
         projector.set_option("tail_cus", 0)
+
+
+def test_compute_full_handoff(pkg, orc, monkeypatch, tmp_path):
+    """computeFull (project_cloud.cu:437-493): the model receives the resident fp16
+    {1,5,H,W} tensor itself (zero copy, same stream) and its output goes through
+    convertTo(CV_8UC3, 255.0).  The U-Net is out of scope (its weights are an LFS pointer), so the
+    stand-in model returns the three colour planes: half(v / 255) * 255 rounds back to v, hence
+    colour must equal the prefiltered image and the tensor seen by the model the oracle's."""
+    torch = pytest.importorskip("torch")
+    n, W, H = 50_000, 160, 128
+    xyzw, rgba = orc.generate("room_shell", 5, 0, n, n)
+    cal = pkg.benchmark_calibration(W, H)
+    E = pkg.orbit_pose(12)
+    ref = orc.project(xyzw, rgba, orc.compose_projection(cal.getIntrinsicsMatrix(), E), W, H)
+    rf = orc.filter(ref["depth_bits"], ref["img"])
+    seen = {}
+
+    class Planes(torch.nn.Module):
+        def forward(self, x):
+            return x[:, 0:3]
+
+    def model(x):
+        seen["ptr"], seen["copy"] = x.data_ptr(), x.clone()
+        return Planes()(x)
+
+    pc = pkg.ProjectCloud(xyzw, rgba)
+    color = np.empty((H, W, 3), np.uint8)
+    depth = np.empty((H, W), np.float32)
+    with pytest.raises(pkg.RtrError):
+        pc.computeFull(cal, E, color, depth)          # no model given
+    pc.set_model(model)
+    assert pc.computeFull(cal, E, color, depth) == 1
+    assert seen["ptr"] == pc.tensor_device_buffer().ptr   # the library's buffer, not a copy
+    got = seen["copy"].cpu().numpy().view(np.uint16).reshape(5, H, W)
+    assert np.array_equal(got, rf["tensor"])
+    assert np.array_equal(color, rf["img"])
+    assert np.array_equal(depth.view(np.uint32), rf["depth"].view(np.uint32))
+    pc.projector.close()
+    # the reference's way: a TorchScript file under $HOME/.render_cache (project_cloud.cu:225-246)
+    monkeypatch.setenv("HOME", str(tmp_path))
+    (tmp_path / ".render_cache").mkdir()
+    torch.jit.script(Planes()).save(str(tmp_path / ".render_cache" / "model.pt"))
+    with pytest.raises(FileNotFoundError):
+        pkg.ProjectCloud(xyzw, rgba, "missing.pt")
+    pc2 = pkg.ProjectCloud(xyzw, rgba, "model.pt")
+    color2 = np.empty((H, W, 3), np.uint8)
+    assert pc2.computeFull(cal, E, color2, None) == 1
+    assert np.array_equal(color2, rf["img"])
+    pc2.projector.close()
