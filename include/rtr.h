@@ -171,7 +171,9 @@ typedef enum {
 int rtr_stream_probe(rtr_ctx *ctx, const float P[16]);
 /* on = 1: every phase is bracketed by hipEvents on the context's stream; on = 2: only the
  * streaming point kernels (RTR_K_MIN_DEPTH, RTR_K_ACCUMULATE), i.e. two event records per
- * frame; 0: off.  rtr_timing_get synchronises and returns the accumulated device time. */
+ * frame; on = 3: like 2 but only every 4th launch is bracketed (a bracket costs ~8 us of stream
+ * time, 3 % of a frame); 0: off.  rtr_timing_get synchronises and returns the accumulated device
+ * time and the number of bracketed launches. */
 int rtr_timing_enable(rtr_ctx *ctx, int on);
 int rtr_timing_reset(rtr_ctx *ctx);
 int rtr_timing_get(rtr_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);

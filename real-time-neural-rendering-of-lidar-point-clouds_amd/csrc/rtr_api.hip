@@ -74,7 +74,8 @@ struct rtr_ctx {
     int opt_debug = 0;          // timing experiments (frames become wrong)
 
     // timing
-    int timing = 0;  // 0 off, 1 every phase, 2 only the streaming kernel (RTR_K_MIN_DEPTH / ACCUMULATE)
+    int timing = 0;  // 0 off, 1 every phase, 2 only the streaming kernel (RTR_K_MIN_DEPTH / ACCUMULATE), 3 = 2 on every 4th launch
+    uint32_t timing_tick = 0;
     struct Span { hipEvent_t a, b; int k; };
     std::vector<Span> pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
@@ -209,7 +210,8 @@ struct Timed {  // brackets one phase with hipEvents on the stream it is launche
     rtr_ctx *c; int k; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
     Timed(rtr_ctx *c_, int k_, hipStream_t s_ = nullptr) : c(c_), k(k_), s(s_ ? s_ : c_->stream) {
         if (!c->timing) return;
-        if (c->timing == 2 && k != RTR_K_MIN_DEPTH && k != RTR_K_ACCUMULATE) return;
+        if (c->timing >= 2 && k != RTR_K_MIN_DEPTH && k != RTR_K_ACCUMULATE) return;
+        if (c->timing == 3 && (c->timing_tick++ & 3u) != 0u) return;  // a bracket costs ~8 us of stream time
         if (c->pool.empty()) {
             (void)hipEventCreate(&a); (void)hipEventCreate(&b);
         } else {
@@ -922,7 +924,8 @@ int rtr_timing_enable(rtr_ctx *c, int on) {
     if (!c) return RTR_ERR_INVALID;
     DevGuard g(c->device);
     (void)collect_timing(c);
-    c->timing = on < 0 ? 0 : (on > 2 ? 1 : on);
+    c->timing = on < 0 ? 0 : (on > 3 ? 1 : on);
+    c->timing_tick = 0;
     return RTR_OK;
 }
 

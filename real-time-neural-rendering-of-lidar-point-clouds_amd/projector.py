@@ -184,7 +184,7 @@ class Projector:
 
     # -- measurement
     def timing_enable(self, on=True):
-        """True / 1: every phase, 2: only the streaming point kernels, False / 0: off."""
+        """True / 1: every phase, 2: only the streaming point kernels, 3: those on every 4th launch, False / 0: off."""
         self._chk(self._lib.rtr_timing_enable(self._ctx, int(on)))
 
     def timing_reset(self):
