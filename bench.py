@@ -52,6 +52,10 @@ def parse():
                     help="N=1: independent frames alternate between this many contexts / HIP streams, so the "
                          "latency-bound tail of frame k (tile sort, tile z-buffer, prefilter) overlaps the "
                          "bandwidth-bound stream of frame k+1")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "collective", "p2p"],
+                    help="N > 1: 'collective' = torch.distributed (RCCL) on the library's buffers; 'p2p' = the library's "
+                         "hand-written exchange over hipIpc-mapped peer buffers; 'auto' (default) times the collectives, "
+                         "then the p2p form (verified against the collectives before and after), and reports the faster")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + several ranks on ONE GPU is a rehearsal of the N>1 logic")
     ap.add_argument("--force-exchange", action="store_true",
@@ -149,8 +153,9 @@ def main():
         projs.append(pj), locals_.append(lj), streams.append(st)
     proj = projs[0]
 
-    def make_renderers(colour):
-        return [pkg.ShardedProjector(lj, colour=colour, force_exchange=args.force_exchange) for lj in locals_]
+    def make_renderers(colour, exchange="collective"):
+        return [pkg.ShardedProjector(lj, colour=colour, force_exchange=args.force_exchange, exchange=exchange)
+                for lj in locals_]
 
     def sync():
         for pj in projs:
@@ -222,23 +227,71 @@ def main():
                           np.array_equal(proj.download(pkg._lib.BUF_IMAGE), ri))
         sync()
 
-    for k in range(args.warmup):
-        render(renderers, k, poses[k])
-    sync()
-    for pj in projs:
-        pj.timing_enable(1 if args.time_all_kernels else 3)  # 3: the dominant kernel, every 4th frame
-        pj.timing_reset()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        render(renderers, k, poses[args.warmup + k])
-    sync()
-    dt = time.perf_counter() - t0
-    timing = {}
-    for pj in projs:
-        for name, (ms, cnt) in pj.timing().items():
-            a, b2 = timing.get(name, (0.0, 0))
-            timing[name] = (a + ms, b2 + cnt)
-        pj.timing_enable(False)
+    def timed_run(rs):
+        """W warm-up frames, then exactly K timed frames between barrier + device sync."""
+        for k in range(args.warmup):
+            render(rs, k, poses[k])
+        sync()
+        for pj in projs:
+            pj.timing_enable(1 if args.time_all_kernels else 3)  # 3: the dominant kernel, every 4th frame
+            pj.timing_reset()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            render(rs, k, poses[args.warmup + k])
+        sync()
+        dt_ = time.perf_counter() - t0
+        if multi:  # the slowest rank's clock counts
+            tmax = torch.tensor([dt_], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_ = float(tmax.item())
+        timing_ = {}
+        for pj in projs:
+            for name, (ms, cnt) in pj.timing().items():
+                a, b2 = timing_.get(name, (0.0, 0))
+                timing_[name] = (a + ms, b2 + cnt)
+            pj.timing_enable(False)
+        return dt_, timing_
+
+    def all_ranks(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    exchange_info = None
+    if multi and args.exchange == "p2p":
+        renderers = make_renderers(colour, "p2p")
+    dt, timing = timed_run(renderers)
+    if multi and args.exchange == "p2p":
+        exchange_info = {"used": "p2p" if all(r.exchange == "p2p" for r in renderers) else "collective (p2p dropped)",
+                         "p2p_note": [r.p2p_note for r in renderers if r.p2p_note]}
+    elif multi and args.exchange == "auto":
+        # The hand-written peer-to-peer exchange, tried after the collectives have been measured:
+        # each renderer checks its first frame against the collectives on every rank; after the
+        # timed frames one more frame is compared and the barrier-timeout words are read.  Only a
+        # run that is clean on every rank, and faster, replaces the collectives' number.
+        exchange_info = {"used": "collective", "collective_ms_per_step": dt / args.steps * 1e3}
+        try:
+            p2p_r = make_renderers(colour, "p2p")
+            dt2, timing2 = timed_run(p2p_r)
+            clean = all(r.exchange == "p2p" for r in p2p_r) and all(pj.p2p_timeouts() == 0 for pj in projs)
+            if clean:
+                k_chk = args.warmup + args.steps - 1
+                render(p2p_r, 0, poses[k_chk]); sync()
+                d_p, i_p = locals_[0].depth_tensor().clone(), locals_[0].image_tensor().clone()
+                render(renderers, 0, poses[k_chk]); sync()
+                clean = bool(torch.equal(d_p, locals_[0].depth_tensor()) and torch.equal(i_p, locals_[0].image_tensor()))
+            note = [r.p2p_note for r in p2p_r if r.p2p_note]
+        except Exception as exc:  # noqa: BLE001
+            clean, dt2, timing2, note = False, None, None, ["%s" % exc]
+        clean = all_ranks(clean)
+        exchange_info["p2p_clean_on_all_ranks"] = clean
+        if dt2 is not None:
+            exchange_info["p2p_ms_per_step"] = dt2 / args.steps * 1e3
+        if note:
+            exchange_info["p2p_note"] = note
+        if clean and dt2 is not None and dt2 < dt:  # both are max-over-ranks: every rank decides alike
+            dt, timing = dt2, timing2
+            exchange_info["used"] = "p2p"
 
     # Reported separately (never part of `value`): the same frames with the one-off Morton
     # reorder + exact per-chunk frustum culling ("cull"), an algorithmic byte reduction.
@@ -259,11 +312,6 @@ def main():
         extra = {"what": "Morton-reordered cloud + exact 256-point-chunk frustum culling (option cull=1); same frames, "
                          "bit-identical output; an algorithmic byte reduction, not a roofline claim",
                  "value": total * m / dte / 1e6, "unit": "Mpoints/s", "ms_per_step": dte / m * 1e3, "steps": m}
-
-    if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     if rank == 0:
         n_local = hi - lo
@@ -296,9 +344,12 @@ def main():
                                       total, args.scene, W, H, " + depth-heuristic prefilter" if with_filter else ""),
                        "points_total": total, "points_per_gpu": n_local, "scene": args.scene,
                        "resolution": [W, H], "prefilter": with_filter,
-                       "parallelism": ("point-shard x%d, %s all-reduce MIN(depth) + %s SUM(accum), %d frames in "
-                                       "flight" % (world, "RCCL" if args.backend == "nccl" else "gloo", colour,
-                                                   depth_k)) if multi else
+                       "parallelism": (("point-shard x%d, hand-written peer-to-peer exchange over hipIpc-mapped buffers: "
+                                        "MIN(depth), SUM(accum) + slice resolve, %d frames in flight" % (world, depth_k))
+                                       if (exchange_info or {}).get("used") == "p2p" else
+                                       ("point-shard x%d, %s all-reduce MIN(depth) + %s SUM(accum), %d frames in "
+                                        "flight" % (world, "RCCL" if args.backend == "nccl" else "gloo", colour,
+                                                    depth_k))) if multi else
                        ("single GPU" + (", %d frames in flight" % depth_k if depth_k > 1 else ""))},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -311,6 +362,8 @@ def main():
             "parity_vs_oracle": parity,
             "with_chunk_culling": extra,
         }
+        if exchange_info is not None:
+            out["exchange"] = exchange_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(entry.load_oracle(), pkg, args)
         print(json.dumps(out))

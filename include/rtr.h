@@ -145,6 +145,29 @@ int rtr_resolve(rtr_ctx *ctx);                         /* render.cu:132-163 */
 int rtr_resolve_range(rtr_ctx *ctx, const void *acc_dev, uint64_t first_pixel, uint64_t count);
 int rtr_filter(rtr_ctx *ctx);                          /* project_cloud.cu:331-392 */
 
+/* ---- 5b. peer-to-peer exchange for the phase calls (one process per GPU on one node) ----
+ * The hand-written counterpart of the two collectives above: every rank maps
+ * the other ranks' frame buffers through hipIpc and pulls over xGMI.  Set up once per
+ * resolution: each rank calls rtr_p2p_export, the handle blocks are exchanged by the host (any
+ * transport: they are plain bytes), then every rank calls rtr_p2p_open with all of them.
+ *   rtr_clear -> rtr_min_depth_pass -> rtr_p2p_min_depth     (RTR_BUF_DEPTH := MIN over ranks)
+ *   -> rtr_accumulate_pass -> rtr_p2p_sum_resolve             (RTR_BUF_IMAGE := resolve(SUM of
+ *   RTR_BUF_ACCUM over ranks); RTR_BUF_ACCUM itself stays local) -> rtr_filter (optional)
+ * All ranks must issue the same sequence of rtr_p2p_* calls.  A rank that does not arrive
+ * within the barrier timeout (2 s) is flagged in rtr_p2p_status; the frame is then undefined and
+ * the caller should fall back to the collectives.  rtr_set_resolution closes the mapping. */
+#define RTR_P2P_MAX_RANKS 16
+typedef struct rtr_p2p_handles {
+    unsigned char depth[64], accum[64], image[64], reduced[64], flags[64]; /* hipIpcMemHandle_t each; image and
+                                                                               reduced are exchange copies */
+} rtr_p2p_handles;
+int rtr_p2p_export(rtr_ctx *ctx, rtr_p2p_handles *mine);
+int rtr_p2p_open(rtr_ctx *ctx, int rank, int world, const rtr_p2p_handles *all /* [world] */);
+int rtr_p2p_close(rtr_ctx *ctx);
+int rtr_p2p_min_depth(rtr_ctx *ctx);
+int rtr_p2p_sum_resolve(rtr_ctx *ctx);
+int rtr_p2p_status(rtr_ctx *ctx, uint32_t *barrier_timeouts);
+
 /* ---- 6. device-resident buffers (owned by the context, valid until the next
  *         rtr_set_resolution / rtr_destroy) ---------------------------------------- */
 typedef enum {

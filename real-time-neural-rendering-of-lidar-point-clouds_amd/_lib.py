@@ -19,11 +19,13 @@ SYMBOLS = [
     "rtr_project_filtered", "rtr_render", "rtr_clear", "rtr_min_depth_pass", "rtr_accumulate_pass", "rtr_resolve",
     "rtr_filter", "rtr_device_buffer", "rtr_download_buffer", "rtr_timing_enable", "rtr_timing_reset",
     "rtr_timing_get", "rtr_set_option", "rtr_stream_probe", "rtr_resolve_range", "rtr_reorder_points", "rtr_reset_stream",
+    "rtr_p2p_export", "rtr_p2p_open", "rtr_p2p_close", "rtr_p2p_min_depth", "rtr_p2p_sum_resolve", "rtr_p2p_status",
 ]
 
 RTR_OK, RTR_ERR_INVALID, RTR_ERR_HIP, RTR_ERR_NO_OUTPUT, RTR_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 BUF_DEPTH, BUF_ACCUM, BUF_IMAGE, BUF_TENSOR, BUF_MASK, BUF_MINMAX = range(6)
 K_CLEAR, K_MIN_DEPTH, K_ACCUMULATE, K_RESOLVE, K_FILTER, K_PROBE, K_TILE, K_BIN = range(8)
+P2P_HANDLES_BYTES = 5 * 64  # sizeof(rtr_p2p_handles)
 KERNEL_NAMES = ["clear", "min_depth", "accumulate", "resolve", "filter", "probe", "tile", "bin"]
 SCENES = {"uniform_box": 0, "room_shell": 1}
 EMPTY_DEPTH = 0x7F7FFFFF
@@ -94,6 +96,12 @@ def lib():
     L.rtr_set_option.argtypes = [vp, C.c_char_p, i32]
     L.rtr_stream_probe.argtypes = [vp, vp]
     L.rtr_timing_get.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64)]
+    L.rtr_p2p_export.argtypes = [vp, vp]
+    L.rtr_p2p_open.argtypes = [vp, i32, i32, vp]
+    L.rtr_p2p_close.argtypes = [vp]
+    L.rtr_p2p_min_depth.argtypes = [vp]
+    L.rtr_p2p_sum_resolve.argtypes = [vp]
+    L.rtr_p2p_status.argtypes = [vp, C.POINTER(C.c_uint32)]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("rtr_last_error", "rtr_default_params"):

@@ -73,6 +73,20 @@ struct rtr_ctx {
     int opt_grid = rtr::kDefaultPointGrid;  // workgroups of the point kernels
     int opt_debug = 0;          // timing experiments (frames become wrong)
 
+    // peer-to-peer exchange (rtr_p2p_*): own exchange buffers, the peers' mappings, barrier state
+    struct P2P {
+        uint32_t *red = nullptr;          // [npix] reduced depth; this rank writes its slice, peers read it
+        uint8_t *ximg = nullptr;          // [3 * npix] resolved image; same (the prefilter rewrites RTR_BUF_IMAGE in place)
+        uint32_t *flags = nullptr;        // [RTR_P2P_MAX_RANKS] uncached: barrier counters written by the peers
+        uint32_t *status_host = nullptr;  // mapped host word: barrier timeouts
+        uint32_t *status_dev = nullptr;
+        rtr::PeerSet depth{}, accum{}, image{}, reduced{}, flags_of{};
+        void *opened[5][RTR_P2P_MAX_RANKS] = {};
+        int rank = 0, world = 0;
+        uint32_t seq = 0;
+        bool open = false;
+    } p2p;
+
     // timing
     int timing = 0;  // 0 off, 1 every phase, 2 only the streaming kernel (RTR_K_MIN_DEPTH / ACCUMULATE), 3 = 2 on every 4th launch
     uint32_t timing_tick = 0;
@@ -118,8 +132,24 @@ void dfree(T *&p) {
     p = nullptr;
 }
 
+void p2p_release(rtr_ctx *c) {  // the peers' mappings and this rank's exchange buffers
+    auto &q = c->p2p;
+    for (auto &kind : q.opened)
+        for (auto &ptr : kind) {
+            if (ptr) (void)hipIpcCloseMemHandle(ptr);
+            ptr = nullptr;
+        }
+    dfree(q.red);
+    dfree(q.ximg);
+    dfree(q.flags);
+    q.open = false;
+    q.world = 0;
+    q.seq = 0;
+}
+
 void free_frame(rtr_ctx *c) {
     c->list_valid = false;
+    p2p_release(c);
     dfree(c->depth); dfree(c->acc); dfree(c->img); dfree(c->mask); dfree(c->part_min); dfree(c->part_max); dfree(c->tensor);
     for (int i = 1; i <= 8; ++i) dfree(c->lv.lv[i]);
     for (auto &f : c->fs) {
@@ -358,6 +388,7 @@ int rtr_destroy(rtr_ctx *c) {
     free_cloud(c);
     dfree(c->minmax);
     if (c->stats_host) (void)hipHostFree(c->stats_host);
+    if (c->p2p.status_host) (void)hipHostFree(c->p2p.status_host);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return RTR_OK;
@@ -880,6 +911,153 @@ int rtr_project(rtr_ctx *c, const float P[16], uint8_t *host_img, float *host_de
 
 int rtr_project_filtered(rtr_ctx *c, const float P[16], uint8_t *host_img, float *host_depth) {
     return frame_to_host(c, P, host_img, host_depth, 1);
+}
+
+// ---- peer-to-peer exchange ------------------------------------------------------------
+
+static int p2p_alloc(rtr_ctx *c) {  // this rank's exchange buffers (per resolution)
+    auto &q = c->p2p;
+    const size_t npix = (size_t)c->W * c->H;
+    if (!q.red) HIP_TRY(c, hipMalloc((void **)&q.red, ((npix + 3) & ~(size_t)3) * sizeof(uint32_t)));
+    if (!q.ximg) HIP_TRY(c, hipMalloc((void **)&q.ximg, (npix * 3 + 15) & ~(size_t)15));
+    if (!q.flags) {
+        HIP_TRY(c, hipExtMallocWithFlags((void **)&q.flags, 4096, hipDeviceMallocUncached));
+        HIP_TRY(c, hipMemsetAsync(q.flags, 0, 4096, c->stream));
+        HIP_TRY(c, sync_streams(c));
+    }
+    if (!q.status_host) {
+        HIP_TRY(c, hipHostMalloc((void **)&q.status_host, sizeof(uint32_t), hipHostMallocMapped));
+        *q.status_host = 0;
+        void *d = nullptr;
+        HIP_TRY(c, hipHostGetDevicePointer(&d, q.status_host, 0));
+        q.status_dev = static_cast<uint32_t *>(d);
+    }
+    return RTR_OK;
+}
+
+int rtr_p2p_export(rtr_ctx *c, rtr_p2p_handles *mine) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, mine != nullptr, "handles is NULL");
+    if (int rc = check_frame(c)) return rc;
+    static_assert(sizeof(hipIpcMemHandle_t) <= 64, "handle block too small");
+    DevGuard g(c->device);
+    HIP_TRY(c, sync_streams(c));
+    if (int rc = p2p_alloc(c)) return rc;
+    memset(mine, 0, sizeof *mine);
+    void *bufs[5] = {c->depth, c->acc, c->p2p.ximg, c->p2p.red, c->p2p.flags};
+    unsigned char *dst[5] = {mine->depth, mine->accum, mine->image, mine->reduced, mine->flags};
+    for (int k = 0; k < 5; ++k) {
+        hipIpcMemHandle_t h;
+        HIP_TRY(c, hipIpcGetMemHandle(&h, bufs[k]));
+        memcpy(dst[k], &h, sizeof h);
+    }
+    return RTR_OK;
+}
+
+int rtr_p2p_open(rtr_ctx *c, int rank, int world, const rtr_p2p_handles *all) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, all != nullptr, "handles is NULL");
+    NEED(c, world >= 1 && world <= RTR_P2P_MAX_RANKS && rank >= 0 && rank < world, "bad rank / world");
+    if (int rc = check_frame(c)) return rc;
+    DevGuard g(c->device);
+    HIP_TRY(c, sync_streams(c));
+    auto &q = c->p2p;
+    NEED(c, q.red && q.ximg && q.flags, "rtr_p2p_export has not been called for this resolution");
+    NEED(c, !q.open, "already open (rtr_p2p_close first)");
+    rtr::PeerSet *sets[5] = {&q.depth, &q.accum, &q.image, &q.reduced, &q.flags_of};
+    void *own[5] = {c->depth, c->acc, q.ximg, q.red, q.flags};
+    for (int r = 0; r < world; ++r) {
+        const unsigned char *src[5] = {all[r].depth, all[r].accum, all[r].image, all[r].reduced, all[r].flags};
+        for (int k = 0; k < 5; ++k) {
+            if (r == rank) {
+                sets[k]->p[r] = own[k];
+                continue;
+            }
+            hipIpcMemHandle_t h;
+            memcpy(&h, src[k], sizeof h);
+            void *ptr = nullptr;
+            hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) {
+                int rc = fail(c, RTR_ERR_HIP, "hipIpcOpenMemHandle (rank %d, buffer %d) failed: %s", r, k, hipGetErrorString(e));
+                p2p_release(c);
+                return rc;
+            }
+            q.opened[k][r] = ptr;
+            sets[k]->p[r] = ptr;
+        }
+    }
+    q.rank = rank;
+    q.world = world;
+    q.seq = 0;
+    q.open = true;
+    *q.status_host = 0;
+    return RTR_OK;
+}
+
+int rtr_p2p_close(rtr_ctx *c) {
+    if (!c) return RTR_ERR_INVALID;
+    DevGuard g(c->device);
+    HIP_TRY(c, sync_streams(c));
+    p2p_release(c);
+    return RTR_OK;
+}
+
+int rtr_p2p_status(rtr_ctx *c, uint32_t *barrier_timeouts) {
+    if (!c || !barrier_timeouts) return RTR_ERR_INVALID;
+    *barrier_timeouts = c->p2p.status_host ? *c->p2p.status_host : 0u;
+    return RTR_OK;
+}
+
+namespace {
+constexpr unsigned long long kP2PTimeoutTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
+struct Slice { size_t chunk, first, count; };
+Slice p2p_slice(const rtr_ctx *c) {  // pixels owned by this rank: slices start on pixel quads
+    const size_t npix = (size_t)c->W * c->H, w = (size_t)c->p2p.world;
+    Slice s;
+    s.chunk = (((npix + w - 1) / w) + 3) & ~(size_t)3;
+    s.first = s.chunk * (size_t)c->p2p.rank;
+    if (s.first > npix) s.first = npix;
+    s.count = (npix - s.first) < s.chunk ? npix - s.first : s.chunk;
+    return s;
+}
+void p2p_barrier(rtr_ctx *c) {
+    auto &q = c->p2p;
+    rtr::launch_p2p_sync(c->stream, q.flags, q.flags_of, q.rank, q.world, ++q.seq, q.status_dev, kP2PTimeoutTicks);
+}
+}  // namespace
+
+int rtr_p2p_min_depth(rtr_ctx *c) {
+    if (!c) return RTR_ERR_INVALID;
+    if (int rc = check_frame(c)) return rc;
+    NEED(c, c->p2p.open, "rtr_p2p_open has not been called");
+    DevGuard g(c->device);
+    auto &q = c->p2p;
+    const Slice s = p2p_slice(c);
+    const size_t npix = (size_t)c->W * c->H;
+    p2p_barrier(c);  // every rank's local depth is complete
+    rtr::launch_p2p_depth_reduce(c->stream, q.depth, q.red, s.first, s.count, q.world);
+    p2p_barrier(c);  // every slice is reduced; nobody reads the local depth buffers any more
+    rtr::launch_p2p_gather_dwords(c->stream, q.reduced, c->depth, s.chunk, npix, -1);
+    return launch_check(c, "p2p_min_depth");
+}
+
+int rtr_p2p_sum_resolve(rtr_ctx *c) {
+    if (!c) return RTR_ERR_INVALID;
+    if (int rc = check_frame(c)) return rc;
+    NEED(c, c->p2p.open, "rtr_p2p_open has not been called");
+    DevGuard g(c->device);
+    auto &q = c->p2p;
+    const Slice s = p2p_slice(c);
+    const size_t npix = (size_t)c->W * c->H, nbytes = npix * 3;
+    p2p_barrier(c);  // every rank's accumulators are complete (and its reduced-depth slice has been read)
+    rtr::launch_p2p_acc_resolve(c->stream, q.accum, q.ximg, s.first, s.count, q.world);
+    p2p_barrier(c);  // every image slice is resolved; nobody reads the accumulators any more
+    rtr::launch_p2p_gather_dwords(c->stream, q.image, reinterpret_cast<uint32_t *>(c->img), s.chunk * 3 / 4, nbytes / 4, -1);
+    if (nbytes % 4) {
+        const int owner = (int)((npix - 1) / s.chunk);
+        rtr::launch_p2p_gather_tail(c->stream, q.image, c->img, nbytes & ~(size_t)3, nbytes, owner, -1);
+    }
+    return launch_check(c, "p2p_sum_resolve");
 }
 
 // ---- buffers -----------------------------------------------------------------------

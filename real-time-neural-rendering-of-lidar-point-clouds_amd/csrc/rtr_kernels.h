@@ -75,6 +75,18 @@ void launch_resolve(hipStream_t s, const uint32_t *acc, uint8_t *img, size_t npi
 void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, uint8_t *img, uint8_t *mask,
                    uint16_t *tensor, uint32_t *minmax, uint32_t *part_min, uint32_t *part_max, int W, int H,
                    float strength, float thr, int pyramid_parts);
+// peer-to-peer exchange (see the comment on k_p2p_sync): p[r] = rank r's buffer as mapped into this process
+constexpr int kMaxPeers = 16;
+struct PeerSet {
+    void *p[kMaxPeers];
+};
+void launch_p2p_sync(hipStream_t s, uint32_t *my_flags, const PeerSet &peer_flags, int rank, int world, uint32_t seq,
+                     uint32_t *status, unsigned long long timeout_ticks);
+void launch_p2p_depth_reduce(hipStream_t s, const PeerSet &depth, uint32_t *red, size_t first, size_t count, int world);
+void launch_p2p_gather_dwords(hipStream_t s, const PeerSet &src, uint32_t *dst, size_t chunk_dw, size_t n_dw,
+                              int skip_owner);  // skip_owner < 0: copy every slice
+void launch_p2p_gather_tail(hipStream_t s, const PeerSet &src, uint8_t *dst, size_t from, size_t to, int owner, int rank);
+void launch_p2p_acc_resolve(hipStream_t s, const PeerSet &acc, uint8_t *img, size_t first, size_t count, int world);
 void launch_generate(hipStream_t s, int scene, uint64_t seed, uint64_t first, uint64_t count, uint64_t total,
                      float *x, float *y, float *z, uint32_t *rgba);
 void launch_aos_to_soa(hipStream_t s, const uint8_t *xyz, size_t xyz_stride, const uint8_t *rgb, size_t rgb_stride,

@@ -1569,6 +1569,134 @@ void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, u
 }
 
 // ---------------------------------------------------------------------------------
+// Peer-to-peer exchange between the contexts of one node (one process per GPU,
+// the peers' frame buffers mapped through hipIpc, xGMI reads).  The pixel range is cut into
+// `world` slices of `chunk` pixels; a rank reduces ITS slice over all ranks' buffers (pull), then
+// every rank collects the reduced slices.  Data only ever crosses a process boundary between
+// kernels -- a buffer is written by one launch and read remotely by a later one, ordered by the
+// flag barrier below -- so ordinary (coarse-grained) device memory is enough; only the flags
+// live in uncached memory and are accessed with system-scope atomics.
+//
+// Barrier: every rank owns flags[world]; a rank entering barrier number `seq` stores seq into
+// flags[rank] of every peer and then waits until its own flags[r] >= seq for all r.  All ranks run
+// the same sequence of barriers, so the counter can simply increase.  The wait is bounded
+// (wall_clock64 ticks): a rank that never arrives makes the others give up, count the event in
+// `status` (mapped host memory) and go on -- the host then drops back to the collectives.
+__global__ void k_p2p_sync(uint32_t *__restrict__ my_flags, PeerSet peer_flags, int rank, int world, uint32_t seq,
+                           uint32_t *__restrict__ status, unsigned long long timeout_ticks) {
+    const int t = threadIdx.x;
+    if (t >= world || t == rank) return;
+    __hip_atomic_store(static_cast<uint32_t *>(peer_flags.p[t]) + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(my_flags + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        if (wall_clock64() - t0 > timeout_ticks) {
+            *reinterpret_cast<volatile uint32_t *>(status) = 1u;  // plain store: the word lives in host memory
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+// depth: red[first .. first + count) = MIN over ranks of depth_r[...] (u32 bit patterns, render.cu:81)
+__global__ __launch_bounds__(kBlock) void k_p2p_depth_reduce(PeerSet depth, uint32_t *__restrict__ red, size_t first,
+                                                             size_t count, int world) {
+    const size_t q = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+    if (q >= count) return;
+    if (q + 4 <= count) {
+        uint4 m = *reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(depth.p[0]) + first + q);
+        for (int r = 1; r < world; ++r) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(depth.p[r]) + first + q);
+            m.x = v.x < m.x ? v.x : m.x; m.y = v.y < m.y ? v.y : m.y;
+            m.z = v.z < m.z ? v.z : m.z; m.w = v.w < m.w ? v.w : m.w;
+        }
+        *reinterpret_cast<uint4 *>(red + first + q) = m;
+    } else {
+        for (size_t i = q; i < count; ++i) {
+            uint32_t m = static_cast<const uint32_t *>(depth.p[0])[first + i];
+            for (int r = 1; r < world; ++r) {
+                const uint32_t v = static_cast<const uint32_t *>(depth.p[r])[first + i];
+                m = v < m ? v : m;
+            }
+            red[first + i] = m;
+        }
+    }
+}
+
+// dst[p] = src_owner(p)[p] for every element p in [0, n): collects the slices every rank reduced.
+// Elements are dwords (depth: one per pixel; image: 3 bytes per pixel, slices start on pixel
+// quads so they are whole dwords; `tail` trailing bytes of the last slice are copied one by one).
+__global__ __launch_bounds__(kBlock) void k_p2p_gather(PeerSet src, uint32_t *__restrict__ dst, size_t chunk_dw,
+                                                       size_t n_dw, int skip_owner) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_dw) return;
+    const int owner = (int)(i / chunk_dw);
+    if (owner == skip_owner) return;  // this rank's own slice when it is already in place
+    dst[i] = static_cast<const uint32_t *>(src.p[owner])[i];
+}
+__global__ void k_p2p_gather_tail(PeerSet src, uint8_t *__restrict__ dst, size_t from, size_t to, int owner, int rank) {
+    if (owner == rank) return;
+    for (size_t i = from + threadIdx.x; i < to; i += blockDim.x) dst[i] = static_cast<const uint8_t *>(src.p[owner])[i];
+}
+
+// colour: img[first .. first + count) = resolve(SUM over ranks of acc_r[...]) (render.cu:125-128,147-162;
+// u32 sums wrap like the reference's atomicAdd).  first % 4 == 0; four pixels per thread.
+__global__ __launch_bounds__(kBlock) void k_p2p_acc_resolve(PeerSet acc, uint8_t *__restrict__ img, size_t first,
+                                                            size_t count, int world) {
+    const size_t q = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+    if (q >= count) return;
+    const int cnt = (count - q) < 4 ? (int)(count - q) : 4;
+    uint32_t out[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint4 a = make_uint4(0, 0, 0, 0);
+        if (k < cnt)
+            for (int r = 0; r < world; ++r) {
+                const uint4 v = static_cast<const uint4 *>(acc.p[r])[first + q + k];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+        const uint32_t c = a.w;
+        out[3 * k + 0] = c ? a.x / c : 0u;
+        out[3 * k + 1] = c ? a.y / c : 0u;
+        out[3 * k + 2] = c ? a.z / c : 0u;
+    }
+    uint8_t *o = img + (first + q) * 3;
+    if (cnt == 4) {
+        uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
+        o32[0] = (out[0] & 0xFF) | ((out[1] & 0xFF) << 8) | ((out[2] & 0xFF) << 16) | ((out[3] & 0xFF) << 24);
+        o32[1] = (out[4] & 0xFF) | ((out[5] & 0xFF) << 8) | ((out[6] & 0xFF) << 16) | ((out[7] & 0xFF) << 24);
+        o32[2] = (out[8] & 0xFF) | ((out[9] & 0xFF) << 8) | ((out[10] & 0xFF) << 16) | ((out[11] & 0xFF) << 24);
+    } else {
+        for (int k = 0; k < 3 * cnt; ++k) o[k] = (uint8_t)out[k];
+    }
+}
+
+void launch_p2p_sync(hipStream_t s, uint32_t *my_flags, const PeerSet &peer_flags, int rank, int world, uint32_t seq,
+                     uint32_t *status, unsigned long long timeout_ticks) {
+    hipLaunchKernelGGL(k_p2p_sync, dim3(1), dim3(64), 0, s, my_flags, peer_flags, rank, world, seq, status, timeout_ticks);
+}
+void launch_p2p_depth_reduce(hipStream_t s, const PeerSet &depth, uint32_t *red, size_t first, size_t count, int world) {
+    if (count == 0) return;
+    const size_t quads = (count + 3) / 4;
+    hipLaunchKernelGGL(k_p2p_depth_reduce, dim3((unsigned)((quads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, depth, red,
+                       first, count, world);
+}
+void launch_p2p_gather_dwords(hipStream_t s, const PeerSet &src, uint32_t *dst, size_t chunk_dw, size_t n_dw,
+                              int skip_owner) {
+    if (n_dw == 0) return;
+    hipLaunchKernelGGL(k_p2p_gather, dim3((unsigned)((n_dw + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, src, dst, chunk_dw,
+                       n_dw, skip_owner);
+}
+void launch_p2p_gather_tail(hipStream_t s, const PeerSet &src, uint8_t *dst, size_t from, size_t to, int owner, int rank) {
+    if (to > from) hipLaunchKernelGGL(k_p2p_gather_tail, dim3(1), dim3(64), 0, s, src, dst, from, to, owner, rank);
+}
+void launch_p2p_acc_resolve(hipStream_t s, const PeerSet &acc, uint8_t *img, size_t first, size_t count, int world) {
+    if (count == 0) return;
+    const size_t quads = (count + 3) / 4;
+    hipLaunchKernelGGL(k_p2p_acc_resolve, dim3((unsigned)((quads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, acc, img,
+                       first, count, world);
+}
+
+// ---------------------------------------------------------------------------------
 // synthetic scenes generated straight into HBM; op-for-op the same
 // arithmetic as orc_generate so CPU, GPU shards and fixtures agree bit for bit.
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {

@@ -182,6 +182,32 @@ class Projector:
         self._chk(self._lib.rtr_download_buffer(self._ctx, which, _vp(out), out.nbytes))
         return out
 
+    # -- peer-to-peer exchange (rtr.h section 5b)
+    def p2p_export(self):
+        """-> bytes: this rank's handle block (exchange it with the other ranks, then p2p_open)."""
+        buf = C.create_string_buffer(L.P2P_HANDLES_BYTES)
+        self._chk(self._lib.rtr_p2p_export(self._ctx, buf))
+        return buf.raw
+
+    def p2p_open(self, rank, world, handles):
+        """handles: the `world` handle blocks in rank order."""
+        assert len(handles) == world and all(len(h) == L.P2P_HANDLES_BYTES for h in handles)
+        self._chk(self._lib.rtr_p2p_open(self._ctx, rank, world, C.create_string_buffer(b"".join(handles))))
+
+    def p2p_close(self):
+        self._chk(self._lib.rtr_p2p_close(self._ctx))
+
+    def p2p_min_depth(self):
+        self._chk(self._lib.rtr_p2p_min_depth(self._ctx))
+
+    def p2p_sum_resolve(self):
+        self._chk(self._lib.rtr_p2p_sum_resolve(self._ctx))
+
+    def p2p_timeouts(self):
+        n = C.c_uint32()
+        self._chk(self._lib.rtr_p2p_status(self._ctx, C.byref(n)))
+        return n.value
+
     # -- measurement
     def timing_enable(self, on=True):
         """True / 1: every phase, 2: only the streaming point kernels, 3: those on every 4th launch, False / 0: off."""

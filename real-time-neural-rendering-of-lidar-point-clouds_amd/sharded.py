@@ -11,7 +11,15 @@ Per frame:  clear -> local min-depth pass -> all-reduce MIN(depth)
             -> local accumulate pass against the GLOBAL minimum (the 2 cm window of
                render.cu:106 is relative to the global front surface)
             -> SUM of the accumulators -> resolve (-> prefilter, replicated).
-Colour exchange forms:
+Exchange forms:
+  exchange="collective"  torch.distributed collectives on the library's own buffers (below);
+  exchange="p2p"         the library's hand-written exchange (rtr.h 5b): every rank maps the other
+                         ranks' frame buffers through hipIpc and pulls its pixel slice over xGMI
+                         (MIN of depth, SUM + resolve of colour), four flag barriers per frame, no
+                         host round trip.  The first frame is rendered both ways and compared on
+                         every rank; any difference, error or barrier timeout drops back to the
+                         collectives for good.
+Colour forms of the collective exchange:
   "allreduce"      all-reduce SUM of the 16 B/px accumulators, every rank resolves all pixels;
   "reduce_scatter" reduce-scatter SUM (each rank receives 1/N of the pixels), slice-local
                    resolve, all-gather of the 3 B/px image: about 0.55 x the bytes on the wire.
@@ -79,6 +87,26 @@ class HipLocal:
     def render(self, P, with_filter):
         self.p.render(P, with_filter)
 
+    # peer-to-peer exchange (rtr.h 5b)
+    def p2p_setup(self, rank, world, group):
+        """Exchange the hipIpc handle blocks over `group` and map the peers' buffers."""
+        mine = self.p.p2p_export()
+        blocks = [None] * world
+        dist.all_gather_object(blocks, mine, group=group)
+        self.p.p2p_open(rank, world, blocks)
+
+    def p2p_close(self):
+        self.p.p2p_close()
+
+    def p2p_min_depth(self):
+        self.p.p2p_min_depth()
+
+    def p2p_sum_resolve(self):
+        self.p.p2p_sum_resolve()
+
+    def p2p_timeouts(self):
+        return self.p.p2p_timeouts()
+
 
 class ShardedProjector:
     """Runs the frame sequence over `group`; every rank ends with the full frame.
@@ -88,8 +116,12 @@ class ShardedProjector:
     `HipLocal` in production, an oracle-backed stand-in in the CPU tests.  The
     "reduce_scatter" colour form additionally needs resolve_range() and image_tensor()."""
 
-    def __init__(self, local, group=None, colour="allreduce", force_exchange=False):
-        assert colour in ("allreduce", "reduce_scatter")
+    def __init__(self, local, group=None, colour="allreduce", force_exchange=False, exchange="collective"):
+        assert colour in ("allreduce", "reduce_scatter") and exchange in ("collective", "p2p")
+        self.exchange = exchange
+        self.p2p_note = None        # why the p2p exchange was dropped, if it was
+        self._p2p_res = None        # resolution the peers' buffers are mapped for
+        self._p2p_verified = False
         self.force_exchange = force_exchange  # run the collectives even in a 1-rank group (tests)
         self.local = local
         self.group = group
@@ -113,12 +145,69 @@ class ShardedProjector:
         dist.all_gather_into_tensor(img, mine, group=self.group)
         return True
 
+    # -- peer-to-peer form ---------------------------------------------------------------
+    def _all_agree(self, ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.local.depth_tensor().device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(flag.item())
+
+    def _drop_p2p(self, why):
+        self.exchange, self.p2p_note = "collective", why
+        try:
+            self.local.p2p_close()
+        except Exception:
+            pass
+
+    def _p2p_frame(self, P):
+        lo = self.local
+        lo.clear()
+        lo.min_depth_pass(P)
+        lo.p2p_min_depth()
+        lo.accumulate_pass(P)
+        lo.p2p_sum_resolve()
+
+    def _render_p2p(self, P, with_filter):
+        """-> False if the p2p form is (now) unavailable and the collectives must render the frame."""
+        lo = self.local
+        res = (lo.p.W, lo.p.H)
+        if self._p2p_res != res:  # (re)map the peers' buffers: collective, every rank gets here
+            ok = True
+            try:
+                lo.p2p_setup(self.rank, self.world, self.group)
+            except Exception as e:  # e.g. hipIpc refused
+                ok, why = False, "setup failed: %s" % e
+            if not self._all_agree(ok):
+                self._drop_p2p(why if not ok else "setup failed on another rank")
+                return False
+            self._p2p_res, self._p2p_verified = res, False
+        if not self._p2p_verified:  # first frame: render with the collectives too and compare
+            self._render_collective(P, False)
+            ref_d, ref_i = lo.depth_tensor().clone(), lo.image_tensor().clone()
+            self._p2p_frame(P)
+            same = bool(torch.equal(lo.depth_tensor(), ref_d) and torch.equal(lo.image_tensor(), ref_i))
+            same = same and lo.p2p_timeouts() == 0
+            if not self._all_agree(same):
+                self._drop_p2p("first frame differed from the collectives' (or a barrier timed out)")
+                return False
+            self._p2p_verified = True
+        else:
+            self._p2p_frame(P)
+        if with_filter:
+            lo.filter()
+        return True
+
     def render(self, P, with_filter=False):
         lo = self.local
         exchange = self.world > 1 or (self.force_exchange and dist.is_initialized())
         if not exchange and hasattr(lo, "render"):
             lo.render(P, with_filter)  # no exchange step: the fused whole-frame call
             return
+        if exchange and self.exchange == "p2p" and self._render_p2p(P, with_filter):
+            return
+        self._render_collective(P, with_filter, exchange)
+
+    def _render_collective(self, P, with_filter, exchange=True):
+        lo = self.local
         lo.clear()
         lo.min_depth_pass(P)
         if exchange:

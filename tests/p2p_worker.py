@@ -1,0 +1,56 @@
+"""Worker of test_gpu_p2p.py (one rank of a torch.distributed.run job, all ranks on GPU 0):
+renders a point-sharded cloud with the library's peer-to-peer exchange (hipIpc mappings of the
+other ranks' frame buffers, flag barriers) and checks every rank's frames against the oracle."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+
+def main():
+    W, H, n, frames = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    pkg, orc = entry.load_package(), entry.load_oracle()
+    proj = pkg.Projector(0)
+    lo, hi = pkg.shard_range(n, rank, world)
+    proj.generate_synthetic("room_shell", 11, lo, hi - lo, n)
+    proj.set_resolution(W, H)
+    local = pkg.sharded.HipLocal(proj)
+    local.bind_stream()
+    sp = pkg.ShardedProjector(local, colour="reduce_scatter", exchange="p2p")
+    xyzw, rgba = orc.generate("room_shell", 11, 0, n, n)
+    ok, notes = True, []
+    for k in range(frames):
+        P = pkg.orbit_projection(7 * k, W, H)
+        filt = (k % 2 == 1) and W % 16 == 0
+        sp.render(P, filt)
+        ref = orc.project(xyzw, rgba, P, W, H)
+        rd, ri = ref["depth_bits"], ref["img"]
+        if filt:
+            rf = orc.filter(rd, ri)
+            rd, ri = rf["depth"].view(np.uint32), rf["img"]
+        same = np.array_equal(proj.download(pkg._lib.BUF_DEPTH), rd) and np.array_equal(proj.download(pkg._lib.BUF_IMAGE), ri)
+        if not same:
+            ok = False
+            notes.append("frame %d differs on rank %d" % (k, rank))
+    out = {"rank": rank, "ok": ok, "exchange": sp.exchange, "p2p_note": sp.p2p_note, "timeouts": proj.p2p_timeouts(),
+           "notes": notes}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, out)
+    if rank == 0:
+        print(json.dumps(gathered), flush=True)
+    dist.barrier()
+    proj.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

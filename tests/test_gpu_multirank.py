@@ -36,3 +36,7 @@ def test_two_rank_bench_matches_oracle(extra):
     assert out["n_gpus"] == 2 and out["parity_vs_oracle"] is True
     assert out["config"]["points_total"] == (3_000_000 if "strong" in extra else 6_000_000)
     assert out["roofline"]["bound"] == "hbm" and out["value"] > 0
+    # --exchange auto: the collectives are timed first, then the hand-written peer-to-peer exchange,
+    # which must have matched them before and after its timed frames on both ranks
+    assert out["exchange"]["p2p_clean_on_all_ranks"] is True, out["exchange"]
+    assert out["exchange"]["used"] in ("p2p", "collective")

@@ -1,0 +1,39 @@
+"""-m gpu: the hand-written peer-to-peer exchange (rtr.h 5b) rehearsed with several ranks on ONE
+GPU: every rank is its own process, maps the other ranks' frame buffers through hipIpc and
+synchronises with them through the uncached flag words, exactly as on an 8-GPU node -- only the
+wires differ (same-device reads instead of xGMI).  Frames must equal the oracle's on every rank
+and the exchange must still be the p2p one at the end (no fallback, no barrier timeout)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("ranks,W,H", [(2, 640, 480), (3, 208, 120), (4, 1920, 1080), (3, 100, 50)])
+def test_p2p_exchange_matches_oracle(ranks, W, H):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "p2p_worker.py"), str(W), str(H),
+           "400000", "5"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("[")][-1]
+    out = json.loads(line)
+    assert len(out) == ranks
+    for r in out:
+        assert r["ok"], r
+        assert r["exchange"] == "p2p" and r["timeouts"] == 0, r

@@ -11,7 +11,7 @@ from conftest import HAS_GPU, ROOT
 
 def test_library_exports_every_declared_symbol(pkg):
     hdr = open(os.path.join(ROOT, "include", "rtr.h")).read()
-    declared = sorted(set(re.findall(r"\b(rtr_[a-z_]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(rtr_[a-z0-9_]+)\s*\(", hdr)))
     assert declared, "no declarations found"
     lib = pkg._lib.lib()
     for name in declared:
