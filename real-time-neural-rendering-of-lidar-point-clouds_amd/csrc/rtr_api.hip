@@ -1011,10 +1011,10 @@ int rtr_p2p_status(rtr_ctx *c, uint32_t *barrier_timeouts) {
 namespace {
 constexpr unsigned long long kP2PTimeoutTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
 struct Slice { size_t chunk, first, count; };
-Slice p2p_slice(const rtr_ctx *c) {  // pixels owned by this rank: slices start on pixel quads
+Slice p2p_slice(const rtr_ctx *c) {  // pixels owned by this rank: slices are multiples of 16 pixels
     const size_t npix = (size_t)c->W * c->H, w = (size_t)c->p2p.world;
     Slice s;
-    s.chunk = (((npix + w - 1) / w) + 3) & ~(size_t)3;
+    s.chunk = (((npix + w - 1) / w) + 15) & ~(size_t)15;  // 16 pixels: 64 B of depth, 48 B of image
     s.first = s.chunk * (size_t)c->p2p.rank;
     if (s.first > npix) s.first = npix;
     s.count = (npix - s.first) < s.chunk ? npix - s.first : s.chunk;
@@ -1037,7 +1037,7 @@ int rtr_p2p_min_depth(rtr_ctx *c) {
     p2p_barrier(c);  // every rank's local depth is complete
     rtr::launch_p2p_depth_reduce(c->stream, q.depth, q.red, s.first, s.count, q.world);
     p2p_barrier(c);  // every slice is reduced; nobody reads the local depth buffers any more
-    rtr::launch_p2p_gather_dwords(c->stream, q.reduced, c->depth, s.chunk, npix, -1);
+    rtr::launch_p2p_gather(c->stream, q.reduced, c->depth, s.chunk * 4, npix * 4, -1);
     return launch_check(c, "p2p_min_depth");
 }
 
@@ -1052,11 +1052,7 @@ int rtr_p2p_sum_resolve(rtr_ctx *c) {
     p2p_barrier(c);  // every rank's accumulators are complete (and its reduced-depth slice has been read)
     rtr::launch_p2p_acc_resolve(c->stream, q.accum, q.ximg, s.first, s.count, q.world);
     p2p_barrier(c);  // every image slice is resolved; nobody reads the accumulators any more
-    rtr::launch_p2p_gather_dwords(c->stream, q.image, reinterpret_cast<uint32_t *>(c->img), s.chunk * 3 / 4, nbytes / 4, -1);
-    if (nbytes % 4) {
-        const int owner = (int)((npix - 1) / s.chunk);
-        rtr::launch_p2p_gather_tail(c->stream, q.image, c->img, nbytes & ~(size_t)3, nbytes, owner, -1);
-    }
+    rtr::launch_p2p_gather(c->stream, q.image, c->img, s.chunk * 3, nbytes, -1);
     return launch_check(c, "p2p_sum_resolve");
 }
 

@@ -83,9 +83,8 @@ struct PeerSet {
 void launch_p2p_sync(hipStream_t s, uint32_t *my_flags, const PeerSet &peer_flags, int rank, int world, uint32_t seq,
                      uint32_t *status, unsigned long long timeout_ticks);
 void launch_p2p_depth_reduce(hipStream_t s, const PeerSet &depth, uint32_t *red, size_t first, size_t count, int world);
-void launch_p2p_gather_dwords(hipStream_t s, const PeerSet &src, uint32_t *dst, size_t chunk_dw, size_t n_dw,
-                              int skip_owner);  // skip_owner < 0: copy every slice
-void launch_p2p_gather_tail(hipStream_t s, const PeerSet &src, uint8_t *dst, size_t from, size_t to, int owner, int rank);
+void launch_p2p_gather(hipStream_t s, const PeerSet &src, void *dst, size_t chunk_bytes, size_t nbytes,
+                       int skip_owner);  // skip_owner < 0: copy every slice
 void launch_p2p_acc_resolve(hipStream_t s, const PeerSet &acc, uint8_t *img, size_t first, size_t count, int world);
 void launch_generate(hipStream_t s, int scene, uint64_t seed, uint64_t first, uint64_t count, uint64_t total,
                      float *x, float *y, float *z, uint32_t *rgba);

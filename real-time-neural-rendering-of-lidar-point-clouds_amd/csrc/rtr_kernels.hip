@@ -1622,16 +1622,17 @@ __global__ __launch_bounds__(kBlock) void k_p2p_depth_reduce(PeerSet depth, uint
     }
 }
 
-// dst[p] = src_owner(p)[p] for every element p in [0, n): collects the slices every rank reduced.
-// Elements are dwords (depth: one per pixel; image: 3 bytes per pixel, slices start on pixel
-// quads so they are whole dwords; `tail` trailing bytes of the last slice are copied one by one).
-__global__ __launch_bounds__(kBlock) void k_p2p_gather(PeerSet src, uint32_t *__restrict__ dst, size_t chunk_dw,
-                                                       size_t n_dw, int skip_owner) {
+// dst[i] = src_owner(i)[i] for every 16-byte element i in [0, n16): collects the slices every
+// rank reduced (depth: 4 pixels per element; image: slices are multiples of 16 pixels = 48 bytes,
+// so an element never straddles two owners).  The < 16 trailing bytes of the buffer are copied by
+// k_p2p_gather_tail.
+__global__ __launch_bounds__(kBlock) void k_p2p_gather(PeerSet src, uint4 *__restrict__ dst, size_t chunk16, size_t n16,
+                                                       int skip_owner) {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n_dw) return;
-    const int owner = (int)(i / chunk_dw);
+    if (i >= n16) return;
+    const int owner = (int)(i / chunk16);
     if (owner == skip_owner) return;  // this rank's own slice when it is already in place
-    dst[i] = static_cast<const uint32_t *>(src.p[owner])[i];
+    dst[i] = static_cast<const uint4 *>(src.p[owner])[i];
 }
 __global__ void k_p2p_gather_tail(PeerSet src, uint8_t *__restrict__ dst, size_t from, size_t to, int owner, int rank) {
     if (owner == rank) return;
@@ -1680,14 +1681,17 @@ void launch_p2p_depth_reduce(hipStream_t s, const PeerSet &depth, uint32_t *red,
     hipLaunchKernelGGL(k_p2p_depth_reduce, dim3((unsigned)((quads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, depth, red,
                        first, count, world);
 }
-void launch_p2p_gather_dwords(hipStream_t s, const PeerSet &src, uint32_t *dst, size_t chunk_dw, size_t n_dw,
-                              int skip_owner) {
-    if (n_dw == 0) return;
-    hipLaunchKernelGGL(k_p2p_gather, dim3((unsigned)((n_dw + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, src, dst, chunk_dw,
-                       n_dw, skip_owner);
-}
-void launch_p2p_gather_tail(hipStream_t s, const PeerSet &src, uint8_t *dst, size_t from, size_t to, int owner, int rank) {
-    if (to > from) hipLaunchKernelGGL(k_p2p_gather_tail, dim3(1), dim3(64), 0, s, src, dst, from, to, owner, rank);
+// gathers `nbytes` of a buffer cut into slices of `chunk_bytes` (a multiple of 16) owned by ranks 0, 1, ...
+void launch_p2p_gather(hipStream_t s, const PeerSet &src, void *dst, size_t chunk_bytes, size_t nbytes, int skip_owner) {
+    const size_t n16 = nbytes / 16;
+    if (n16)
+        hipLaunchKernelGGL(k_p2p_gather, dim3((unsigned)((n16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, src, (uint4 *)dst,
+                           chunk_bytes / 16, n16, skip_owner);
+    if (nbytes % 16) {
+        const int owner = (int)((nbytes - 1) / chunk_bytes);
+        if (owner != skip_owner)
+            hipLaunchKernelGGL(k_p2p_gather_tail, dim3(1), dim3(64), 0, s, src, (uint8_t *)dst, n16 * 16, nbytes, owner, -1);
+    }
 }
 void launch_p2p_acc_resolve(hipStream_t s, const PeerSet &acc, uint8_t *img, size_t first, size_t count, int world) {
     if (count == 0) return;

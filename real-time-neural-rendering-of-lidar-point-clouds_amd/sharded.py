@@ -90,9 +90,15 @@ class HipLocal:
     # peer-to-peer exchange (rtr.h 5b)
     def p2p_setup(self, rank, world, group):
         """Exchange the hipIpc handle blocks over `group` and map the peers' buffers."""
-        mine = self.p.p2p_export()
+        try:
+            mine = self.p.p2p_export()
+        except Exception as e:  # every rank still takes part in the gather below
+            mine = "rank %d: %s" % (rank, e)
         blocks = [None] * world
         dist.all_gather_object(blocks, mine, group=group)
+        bad = [b for b in blocks if not isinstance(b, bytes)]
+        if bad:
+            raise RuntimeError("rtr_p2p_export failed: %s" % "; ".join(map(str, bad)))
         self.p.p2p_open(rank, world, blocks)
 
     def p2p_close(self):
