@@ -55,7 +55,6 @@ struct rtr_ctx {
     int cur = 0;
     FrontSet &F() { return fs[cur]; }
     int opt_overlap = 0;        // whole-frame renders run T1 on `front`, everything else on `stream`
-    int opt_front_prio = 0;     // front stream at the lowest priority (experiment)
     int opt_tail_cus = 0;       // CUs per XCD reserved for the tail stream when overlapping (0 = no CU masks)
     hipStream_t front = nullptr;
     hipStream_t masked_tail = nullptr;
@@ -449,9 +448,7 @@ static int set_overlap(rtr_ctx *c, bool on) {
         }
         if (c->stream == c->own_stream) c->stream = c->masked_tail;
     } else {
-        int lo = 0, hi = 0;  // numerically lowest = highest priority
-        HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIP_TRY(c, hipStreamCreateWithPriority(&c->front, hipStreamNonBlocking, c->opt_front_prio ? lo : 0));
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->front, hipStreamNonBlocking));
     }
     for (auto &f : c->fs) {
         hipError_t e = hipEventCreateWithFlags(&f.binned, hipEventDisableTiming);
@@ -505,11 +502,6 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
         NEED(c, value >= 0 && value < 32, "tail_cus must be in 0..31 (CUs per XCD)");
         NEED(c, !c->opt_overlap, "set tail_cus before overlap");
         c->opt_tail_cus = value;
-        return RTR_OK;
-    }
-    if (!strcmp(key, "front_low_priority")) {
-        NEED(c, !c->opt_overlap, "set front_low_priority before overlap");
-        c->opt_front_prio = value != 0;
         return RTR_OK;
     }
     if (!strcmp(key, "overlap")) return set_overlap(c, value != 0);

@@ -38,8 +38,6 @@ def main():
     for setting in args.settings.split(","):
         ov, cus = (int(v) for v in setting.split(":"))
         p.set_option("overlap", 0)
-        p.set_option("front_low_priority", 1 if cus < 0 else 0)
-        cus = max(cus, 0)
         p.set_option("tail_cus", cus)
         try:
             p.set_option("overlap", ov)
