@@ -496,3 +496,40 @@ def test_compute_full_handoff(pkg, orc, monkeypatch, tmp_path):
     assert pc2.computeFull(cal, E, color2, None) == 1
     assert np.array_equal(color2, rf["img"])
     pc2.projector.close()
+
+
+@pytest.mark.parametrize("levels", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("window,strength,thr", [(0.02, 1.025, 0.03), (0.0, 1.0, 0.0), (0.15, 1.2, 0.2)])
+def test_parameter_sweep(pkg, orc, projector, levels, window, strength, thr):
+    """rtr_set_params: every pyramid depth (levels 4 takes the fused one-launch prefilter, the others
+    the level-by-level kernels), window / strength / threshold away from the reference's constants
+    (render.cu:106, project_cloud.cu:23-25) -- whole-frame call and phase calls against the oracle
+    run with the same parameters."""
+    W, H = 640, 480          # 480 >> 6 = 7: rows 448.. lie outside the pyramid for levels 5 and 6
+    xyzw, rgba = orc.generate("room_shell", 21, 0, 600_000, 600_000)
+    P = pkg.orbit_projection(17, W, H)
+    prm = orc.default_params()
+    prm.depth_window, prm.filter_strength, prm.gradient_threshold, prm.levels = window, strength, thr, levels
+    ref = orc.project(xyzw, rgba, P, W, H, params=prm)
+    rf = orc.filter(ref["depth_bits"], ref["img"], params=prm)
+    projector.upload_points(xyzw, rgba)
+    projector.set_resolution(W, H)
+    projector.set_params(depth_window=window, filter_strength=strength, gradient_threshold=thr, levels=levels)
+    try:
+        for phases in (False, True):
+            if phases:
+                projector.clear()
+                projector.min_depth_pass(P)
+                projector.accumulate_pass(P)
+                projector.resolve()
+                assert np.array_equal(projector.download(pkg._lib.BUF_ACCUM), ref["acc"])
+                projector.filter()
+            else:
+                projector.render(P, True)
+            assert np.array_equal(projector.download(pkg._lib.BUF_TENSOR).reshape(5, H, W), rf["tensor"]), phases
+            assert np.array_equal(projector.download(pkg._lib.BUF_MASK), rf["mask"]), phases
+            assert np.array_equal(projector.download(pkg._lib.BUF_DEPTH), rf["depth"].view(np.uint32)), phases
+            assert np.array_equal(projector.download(pkg._lib.BUF_IMAGE), rf["img"]), phases
+            assert np.array_equal(projector.download(pkg._lib.BUF_MINMAX), rf["minmax"]), phases
+    finally:
+        projector.set_params(depth_window=0.02, filter_strength=1.025, gradient_threshold=0.03, levels=4)
