@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: randomized parity sweep (resolutions, point counts, scenes, poses, modes, culling,
-reorder, filter) of the HIP path against the oracle.  Exit code 1 on the first mismatch."""
+reorder, filter, pyramid depth and filter parameters, option overlap) of the HIP path against the
+oracle.  Exit code 1 on the first mismatch."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,8 +13,18 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 p = pkg.Projector(0)
 t0 = time.time()
 for it in range(cases):
+    levels = int(rng.choice([4, 4, 4, 1, 2, 3, 5]))
     W = int(rng.integers(1, 130)) * 16
-    H = int(rng.integers(16, 1300))
+    if levels == 5:
+        W = max(32, W // 32 * 32)
+    H = int(rng.integers(max(16, 1 << levels), 1300))
+    prm = orc.default_params()
+    prm.levels = levels
+    if rng.random() < 0.3:
+        prm.depth_window = float(np.float32(rng.uniform(0.0, 0.2)))
+        prm.filter_strength = float(np.float32(rng.uniform(1.0, 1.2)))
+        prm.gradient_threshold = float(np.float32(rng.uniform(0.0, 0.2)))
+    overlap = int(rng.integers(0, 2))
     n = int(10 ** rng.uniform(0, 6.3))
     scene = ("room_shell", "uniform_box")[int(rng.integers(0, 2))]
     mode, cull, reorder, filt = (int(rng.integers(0, 2)) for _ in range(4))
@@ -27,21 +38,29 @@ for it in range(cases):
     else:
         P = pkg.orbit_projection(int(rng.integers(0, 1000)), W, H)
     p.set_option("mode", mode); p.set_option("cull", cull)
+    p.set_option("overlap", overlap)
+    p.set_params(depth_window=prm.depth_window, filter_strength=prm.filter_strength,
+                 gradient_threshold=prm.gradient_threshold, levels=levels)
     p.upload_points(xyzw, rgba)
     if reorder:
         p.reorder_points()
     p.set_resolution(W, H)
-    ref = orc.project(xyzw, rgba, P, W, H)
+    ref = orc.project(xyzw, rgba, P, W, H, params=prm)
     img, depth = p.project(P)
     ok = np.array_equal(depth.view(np.uint32), ref["depth_bits"]) and np.array_equal(img, ref["img"])
     if ok and filt:
-        rf = orc.filter(ref["depth_bits"], ref["img"])
+        rf = orc.filter(ref["depth_bits"], ref["img"], params=prm)
+        if overlap:  # a few frames back to back, the last one is checked
+            for _ in range(3):
+                p.render(P, True)
         i2, d2 = p.project(P, filtered=True)
         ok = (np.array_equal(d2.view(np.uint32), rf["depth"].view(np.uint32)) and np.array_equal(i2, rf["img"]) and
               np.array_equal(p.download(L.BUF_TENSOR).reshape(5, H, W), rf["tensor"]) and
               np.array_equal(p.download(L.BUF_MASK), rf["mask"]) and np.array_equal(p.download(L.BUF_MINMAX), rf["minmax"]))
     if not ok:
-        print("MISMATCH", dict(it=it, W=W, H=H, n=n, scene=scene, mode=mode, cull=cull, reorder=reorder, filt=filt))
+        print("MISMATCH", dict(it=it, W=W, H=H, n=n, scene=scene, mode=mode, cull=cull, reorder=reorder, filt=filt,
+                               levels=levels, overlap=overlap, window=prm.depth_window, strength=prm.filter_strength,
+                               thr=prm.gradient_threshold))
         sys.exit(1)
     if it % 25 == 0:
         print("case", it, "ok", round(time.time() - t0, 1), "s", flush=True)
