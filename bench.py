@@ -227,6 +227,29 @@ def main():
                           np.array_equal(proj.download(pkg._lib.BUF_IMAGE), ri))
         sync()
 
+    # N > 1 at any size: "multi-GPU result identical to the 1-GPU result" (SURVEY 8d).  Rank 0 holds
+    # the WHOLE cloud once more in a separate context (16 B/pt + lists; 8e8 points are ~45 GB of
+    # 288) and renders pose 0 alone; the sharded frame of the same pose must match bit for bit.
+    parity_single = None
+    if multi and world > 1 and not args.no_parity and total < (1 << 32) and total <= 1_000_000_000:
+        render(renderers, 0, poses[0])
+        sync()
+        if rank == 0:
+            try:
+                whole = pkg.Projector(local_rank)
+                whole.generate_synthetic(args.scene, SEEDS["C3"], 0, total, total)
+                whole.set_resolution(W, H)
+                whole.render(poses[0], with_filter)
+                parity_single = bool(
+                    np.array_equal(whole.download(pkg._lib.BUF_DEPTH), proj.download(pkg._lib.BUF_DEPTH)) and
+                    np.array_equal(whole.download(pkg._lib.BUF_IMAGE), proj.download(pkg._lib.BUF_IMAGE)) and
+                    (not with_filter or np.array_equal(whole.download(pkg._lib.BUF_TENSOR),
+                                                       proj.download(pkg._lib.BUF_TENSOR))))
+                whole.close()
+            except Exception as exc:  # noqa: BLE001  (e.g. out of memory): reported, not fatal
+                parity_single = "not run: %s" % exc
+        sync()
+
     def timed_run(rs):
         """W warm-up frames, then exactly K timed frames between barrier + device sync."""
         for k in range(args.warmup):
@@ -360,6 +383,7 @@ def main():
             "frame_roofline_frac": frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
             "kernel_ms": kern,
             "parity_vs_oracle": parity,
+            "parity_vs_single_gpu": parity_single,
             "with_chunk_culling": extra,
         }
         if exchange_info is not None:

@@ -34,6 +34,7 @@ def test_two_rank_bench_matches_oracle(extra):
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["parity_vs_oracle"] is True
+    assert out["parity_vs_single_gpu"] is True   # rank 0 renders the whole cloud alone and compares
     assert out["config"]["points_total"] == (3_000_000 if "strong" in extra else 6_000_000)
     assert out["roofline"]["bound"] == "hbm" and out["value"] > 0
     # --exchange auto: the collectives are timed first, then the hand-written peer-to-peer exchange,
