@@ -70,7 +70,10 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          reference's structure: two full passes with atomicMin / atomicAdd
  *          (render.cu:53-130).
  *  "auto_reorder": 1 = every later rtr_upload_points / rtr_generate_synthetic is followed by
- *          rtr_reorder_points (default 0: the reference's loader already hands over block order).
+ *          rtr_reorder_points, best effort (skipped when the sort's scratch does not fit).  Default 0
+ *          here; the drop-in classes (rtr::ProjectCloud, the Python mirror) switch it on: the
+ *          reference's loader hands over 0.25 m blocks that are unordered inside, which costs ~13 %
+ *          (DESIGN.md), and those classes never hand the points back.
  *  "cull": 1 = skip 256-point chunks whose bounding box is provably outside the frustum
  *          (exact: same frame; an algorithmic byte reduction, off by default and reported
  *          separately from the roofline figure; needs a spatially coherent point order).

@@ -43,6 +43,7 @@ public:
             }
         }
         check(nullptr, rtr_create(&ctx_, device));
+        check(ctx_, rtr_set_option(ctx_, "auto_reorder", 1));  // one-off Morton sort: the grid's blocks are unordered inside
         check(ctx_, rtr_upload_points(ctx_, xyzw.data(), 16, rgba.data(), 4, xyzw.size() / 4));
     }
     ProjectCloud(const ProjectCloud&) = delete;  // owns device buffers (the reference forgets this)

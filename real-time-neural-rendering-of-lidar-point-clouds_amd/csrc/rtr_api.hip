@@ -554,6 +554,14 @@ int rtr_synchronize(rtr_ctx *c) {
 
 // ---- cloud -------------------------------------------------------------------------
 
+// Option "auto_reorder": best effort.  The sort works on scratch copies and only writes the cloud
+// back at the very end, so a cloud too large for the scratch (or for hipcub's 2^31 item limit)
+// simply stays in the order it was uploaded in.
+static int auto_reorder(rtr_ctx *c) {
+    if (rtr_reorder_points(c) != RTR_OK) (void)hipGetLastError();
+    return RTR_OK;
+}
+
 int rtr_upload_points(rtr_ctx *c, const float *xyz, size_t xs, const uint8_t *rgb, size_t rs, size_t n) {
     if (!c) return RTR_ERR_INVALID;
     NEED(c, n == 0 || (xyz && rgb), "xyz / rgb is NULL");
@@ -587,7 +595,7 @@ int rtr_upload_points(rtr_ctx *c, const float *xyz, size_t xs, const uint8_t *rg
     rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
     HIP_TRY(c, sync_streams(c));
     if (int rc2 = launch_check(c, "aos_to_soa")) return rc2;
-    return c->opt_auto_reorder ? rtr_reorder_points(c) : RTR_OK;
+    return c->opt_auto_reorder ? auto_reorder(c) : RTR_OK;
 }
 
 int rtr_generate_synthetic(rtr_ctx *c, int scene, uint64_t seed, uint64_t first, uint64_t count, uint64_t total) {
@@ -605,7 +613,7 @@ int rtr_generate_synthetic(rtr_ctx *c, int scene, uint64_t seed, uint64_t first,
     rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
     HIP_TRY(c, sync_streams(c));
     if (int rc2 = launch_check(c, "generate")) return rc2;
-    return c->opt_auto_reorder ? rtr_reorder_points(c) : RTR_OK;
+    return c->opt_auto_reorder ? auto_reorder(c) : RTR_OK;
 }
 
 int rtr_reorder_points(rtr_ctx *c) {

@@ -237,7 +237,9 @@ class ProjectCloud:
     post-processes its output (project_cloud.cu:471-487).  `set_model` accepts any callable
     instead of a file."""
 
-    def __init__(self, vertices, colors, modelFilename="", device=0):
+    def __init__(self, vertices, colors, modelFilename="", device=0, reorder=True):
+        """reorder: Morton-sort the cloud once after the upload (the grid's 0.25 m blocks are
+        unordered inside; frames do not depend on the point order)."""
         self.modelFilename = modelFilename
         self.model = None
         self._device = device
@@ -251,6 +253,7 @@ class ProjectCloud:
                                         "camera resolution first)" % path)
             self.model = torch.jit.load(path, map_location="cuda:%d" % device)
         self._p = Projector(device)
+        self._p.set_option("auto_reorder", 1 if reorder else 0)
         self._p.upload_points(vertices, colors)
 
     def set_model(self, model):
