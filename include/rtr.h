@@ -84,7 +84,11 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          the previous frame; results are still ordered on the context's stream.  Default 0:
  *          on MI355X the gain is 0-3 % ("Overlap").  "tail_cus" = t (0..31, set
  *          before "overlap") additionally gives the two streams disjoint CU masks, t CUs of every
- *          XCD for the tail. */
+ *          XCD for the tail.
+ *  "point_grid": workgroups of the grid-stride point kernels (default 1024 = 4 per CU; the
+ *          wave lists are sized for it, so changing it re-allocates them).
+ *  "debug_skip", "probe_variant": measurement aids of tools/kbench.py and tools/probe_variants.py
+ *          (attribute kernel time by switching phases off: frames are WRONG while debug_skip != 0). */
 int rtr_set_option(rtr_ctx *ctx, const char *key, int value);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's
  * own non-blocking stream; NULL means HIP's default stream.  rtr_reset_stream returns to the
