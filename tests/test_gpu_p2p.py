@@ -37,3 +37,43 @@ def test_p2p_exchange_matches_oracle(ranks, W, H):
     for r in out:
         assert r["ok"], r
         assert r["exchange"] == "p2p" and r["timeouts"] == 0, r
+
+
+def test_p2p_single_rank_and_misuse(pkg, orc):
+    """world = 1 needs no peer mapping: the p2p calls must then leave the frame of the plain phase
+    sequence; and the documented misuse cases return errors instead of touching memory."""
+    import numpy as np
+    W, H, n = 208, 120, 100_000
+    xyzw, rgba = orc.generate("room_shell", 3, 0, n, n)
+    P = pkg.orbit_projection(5, W, H)
+    ref = orc.project(xyzw, rgba, P, W, H)
+    p = pkg.Projector(0)
+    try:
+        p.upload_points(xyzw, rgba)
+        p.set_resolution(W, H)
+        with pytest.raises(pkg.RtrError):
+            p.p2p_min_depth()                      # not open
+        with pytest.raises(pkg.RtrError):
+            p.p2p_open(0, 1, [b"\0" * pkg._lib.P2P_HANDLES_BYTES])   # export first
+        mine = p.p2p_export()
+        with pytest.raises(pkg.RtrError):
+            p.p2p_open(0, 17, [mine] * 17)         # more than RTR_P2P_MAX_RANKS
+        with pytest.raises(pkg.RtrError):
+            p.p2p_open(1, 1, [mine])               # rank outside the world
+        p.p2p_open(0, 1, [mine])
+        with pytest.raises(pkg.RtrError):
+            p.p2p_open(0, 1, [mine])               # already open
+        for _ in range(3):
+            p.clear()
+            p.min_depth_pass(P)
+            p.p2p_min_depth()
+            p.accumulate_pass(P)
+            p.p2p_sum_resolve()
+            assert np.array_equal(p.download(pkg._lib.BUF_DEPTH), ref["depth_bits"])
+            assert np.array_equal(p.download(pkg._lib.BUF_IMAGE), ref["img"])
+        assert p.p2p_timeouts() == 0
+        p.set_resolution(W + 16, H)                # closes the mapping
+        with pytest.raises(pkg.RtrError):
+            p.p2p_sum_resolve()
+    finally:
+        p.close()
