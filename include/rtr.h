@@ -165,8 +165,9 @@ int rtr_filter(rtr_ctx *ctx);                          /* project_cloud.cu:331-3
  * the caller should fall back to the collectives.  rtr_set_resolution closes the mapping. */
 #define RTR_P2P_MAX_RANKS 16
 typedef struct rtr_p2p_handles {
-    unsigned char depth[64], accum[64], image[64], reduced[64], flags[64]; /* hipIpcMemHandle_t each; image and
-                                                                               reduced are exchange copies */
+    unsigned char depth[64], accum[64], image[64], reduced[64], flags[64], tiles[64];
+    /* one hipIpcMemHandle_t each: the depth buffer and accumulators, exchange copies of the resolved
+     * image and the reduced depth, the barrier flags, the per-tile occupancy bitmap */
 } rtr_p2p_handles;
 int rtr_p2p_export(rtr_ctx *ctx, rtr_p2p_handles *mine);
 int rtr_p2p_open(rtr_ctx *ctx, int rank, int world, const rtr_p2p_handles *all /* [world] */);

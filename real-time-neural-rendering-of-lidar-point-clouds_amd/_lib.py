@@ -25,7 +25,7 @@ SYMBOLS = [
 RTR_OK, RTR_ERR_INVALID, RTR_ERR_HIP, RTR_ERR_NO_OUTPUT, RTR_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 BUF_DEPTH, BUF_ACCUM, BUF_IMAGE, BUF_TENSOR, BUF_MASK, BUF_MINMAX = range(6)
 K_CLEAR, K_MIN_DEPTH, K_ACCUMULATE, K_RESOLVE, K_FILTER, K_PROBE, K_TILE, K_BIN = range(8)
-P2P_HANDLES_BYTES = 5 * 64  # sizeof(rtr_p2p_handles)
+P2P_HANDLES_BYTES = 6 * 64  # sizeof(rtr_p2p_handles)
 KERNEL_NAMES = ["clear", "min_depth", "accumulate", "resolve", "filter", "probe", "tile", "bin"]
 SCENES = {"uniform_box": 0, "room_shell": 1}
 EMPTY_DEPTH = 0x7F7FFFFF

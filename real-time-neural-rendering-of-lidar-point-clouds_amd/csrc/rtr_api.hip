@@ -77,10 +77,13 @@ struct rtr_ctx {
         uint32_t *red = nullptr;          // [npix] reduced depth; this rank writes its slice, peers read it
         uint8_t *ximg = nullptr;          // [3 * npix] resolved image; same (the prefilter rewrites RTR_BUF_IMAGE in place)
         uint32_t *flags = nullptr;        // [RTR_P2P_MAX_RANKS] uncached: barrier counters written by the peers
+        uint32_t *occ = nullptr;          // [128] one bit per screen tile: this rank's frame has entries there
+        bool occ_current = false;         // occ was computed from the bins that are valid now
+        bool acc_from_bins = false;       // the last accumulate pass used exactly those bins
         uint32_t *status_host = nullptr;  // mapped host word: barrier timeouts
         uint32_t *status_dev = nullptr;
-        rtr::PeerSet depth{}, accum{}, image{}, reduced{}, flags_of{};
-        void *opened[5][RTR_P2P_MAX_RANKS] = {};
+        rtr::PeerSet depth{}, accum{}, image{}, reduced{}, flags_of{}, occ_of{};
+        void *opened[6][RTR_P2P_MAX_RANKS] = {};
         int rank = 0, world = 0;
         uint32_t seq = 0;
         bool open = false;
@@ -141,6 +144,7 @@ void p2p_release(rtr_ctx *c) {  // the peers' mappings and this rank's exchange 
     dfree(q.red);
     dfree(q.ximg);
     dfree(q.flags);
+    dfree(q.occ);
     q.open = false;
     q.world = 0;
     q.seq = 0;
@@ -724,6 +728,7 @@ static bool use_tiles(const rtr_ctx *c) {
 // runs beside T2..F5 of the previous frame (which are latency-bound and leave HBM idle).
 static int bin_points(rtr_ctx *c, const float P[16], bool overlapped = false) {
     c->list_valid = false;
+    c->p2p.occ_current = false;
     hipStream_t s1 = c->stream;
     if (overlapped) {
         c->cur ^= 1;
@@ -785,6 +790,7 @@ int rtr_accumulate_pass(rtr_ctx *c, const float P[16]) {
     // the bins are only usable for the matrix they were built with; otherwise re-project
     // the cloud like the reference does (render.cu:90-98)
     const bool use_bins = use_tiles(c) && c->list_valid && memcmp(c->list_P, P, sizeof c->list_P) == 0;
+    c->p2p.acc_from_bins = use_bins && c->p2p.open && c->p2p.occ_current;
     if (use_bins) {
         Timed t(c, RTR_K_TILE);
         rtr::launch_tile(c->stream, 2, cloud_of(c), c->W, c->H, c->F().bins, c->prm.depth_window, c->depth, c->acc, c->img,
@@ -920,6 +926,7 @@ static int p2p_alloc(rtr_ctx *c) {  // this rank's exchange buffers (per resolut
     const size_t npix = (size_t)c->W * c->H;
     if (!q.red) HIP_TRY(c, hipMalloc((void **)&q.red, ((npix + 3) & ~(size_t)3) * sizeof(uint32_t)));
     if (!q.ximg) HIP_TRY(c, hipMalloc((void **)&q.ximg, (npix * 3 + 15) & ~(size_t)15));
+    if (!q.occ) HIP_TRY(c, hipMalloc((void **)&q.occ, rtr::kP2POccBytes));
     if (!q.flags) {
         HIP_TRY(c, hipExtMallocWithFlags((void **)&q.flags, 4096, hipDeviceMallocUncached));
         HIP_TRY(c, hipMemsetAsync(q.flags, 0, 4096, c->stream));
@@ -944,9 +951,9 @@ int rtr_p2p_export(rtr_ctx *c, rtr_p2p_handles *mine) {
     HIP_TRY(c, sync_streams(c));
     if (int rc = p2p_alloc(c)) return rc;
     memset(mine, 0, sizeof *mine);
-    void *bufs[5] = {c->depth, c->acc, c->p2p.ximg, c->p2p.red, c->p2p.flags};
-    unsigned char *dst[5] = {mine->depth, mine->accum, mine->image, mine->reduced, mine->flags};
-    for (int k = 0; k < 5; ++k) {
+    void *bufs[6] = {c->depth, c->acc, c->p2p.ximg, c->p2p.red, c->p2p.flags, c->p2p.occ};
+    unsigned char *dst[6] = {mine->depth, mine->accum, mine->image, mine->reduced, mine->flags, mine->tiles};
+    for (int k = 0; k < 6; ++k) {
         hipIpcMemHandle_t h;
         HIP_TRY(c, hipIpcGetMemHandle(&h, bufs[k]));
         memcpy(dst[k], &h, sizeof h);
@@ -962,13 +969,13 @@ int rtr_p2p_open(rtr_ctx *c, int rank, int world, const rtr_p2p_handles *all) {
     DevGuard g(c->device);
     HIP_TRY(c, sync_streams(c));
     auto &q = c->p2p;
-    NEED(c, q.red && q.ximg && q.flags, "rtr_p2p_export has not been called for this resolution");
+    NEED(c, q.red && q.ximg && q.flags && q.occ, "rtr_p2p_export has not been called for this resolution");
     NEED(c, !q.open, "already open (rtr_p2p_close first)");
-    rtr::PeerSet *sets[5] = {&q.depth, &q.accum, &q.image, &q.reduced, &q.flags_of};
-    void *own[5] = {c->depth, c->acc, q.ximg, q.red, q.flags};
+    rtr::PeerSet *sets[6] = {&q.depth, &q.accum, &q.image, &q.reduced, &q.flags_of, &q.occ_of};
+    void *own[6] = {c->depth, c->acc, q.ximg, q.red, q.flags, q.occ};
     for (int r = 0; r < world; ++r) {
-        const unsigned char *src[5] = {all[r].depth, all[r].accum, all[r].image, all[r].reduced, all[r].flags};
-        for (int k = 0; k < 5; ++k) {
+        const unsigned char *src[6] = {all[r].depth, all[r].accum, all[r].image, all[r].reduced, all[r].flags, all[r].tiles};
+        for (int k = 0; k < 6; ++k) {
             if (r == rank) {
                 sets[k]->p[r] = own[k];
                 continue;
@@ -1034,8 +1041,13 @@ int rtr_p2p_min_depth(rtr_ctx *c) {
     auto &q = c->p2p;
     const Slice s = p2p_slice(c);
     const size_t npix = (size_t)c->W * c->H;
-    p2p_barrier(c);  // every rank's local depth is complete
-    rtr::launch_p2p_depth_reduce(c->stream, q.depth, q.red, s.first, s.count, q.world);
+    // which screen tiles this rank's frame touches at all (only known when it came from the bins)
+    const bool binned = use_tiles(c) && c->list_valid;
+    rtr::launch_p2p_occupancy(c->stream, binned ? c->F().bins.tile_start : nullptr, c->W, c->H, q.occ);
+    q.occ_current = binned;
+    q.acc_from_bins = false;
+    p2p_barrier(c);  // every rank's local depth (and occupancy) is complete
+    rtr::launch_p2p_depth_reduce(c->stream, q.depth, q.occ_of, q.red, s.first, s.count, q.world, c->W, c->H);
     p2p_barrier(c);  // every slice is reduced; nobody reads the local depth buffers any more
     rtr::launch_p2p_gather(c->stream, q.reduced, c->depth, s.chunk * 4, npix * 4, -1);
     return launch_check(c, "p2p_min_depth");
@@ -1049,8 +1061,10 @@ int rtr_p2p_sum_resolve(rtr_ctx *c) {
     auto &q = c->p2p;
     const Slice s = p2p_slice(c);
     const size_t npix = (size_t)c->W * c->H, nbytes = npix * 3;
+    if (!q.acc_from_bins)  // accumulated by the atomic form (or no depth exchange before): nothing is known
+        rtr::launch_p2p_occupancy(c->stream, nullptr, c->W, c->H, q.occ);
     p2p_barrier(c);  // every rank's accumulators are complete (and its reduced-depth slice has been read)
-    rtr::launch_p2p_acc_resolve(c->stream, q.accum, q.ximg, s.first, s.count, q.world);
+    rtr::launch_p2p_acc_resolve(c->stream, q.accum, q.occ_of, q.ximg, s.first, s.count, q.world, c->W, c->H);
     p2p_barrier(c);  // every image slice is resolved; nobody reads the accumulators any more
     rtr::launch_p2p_gather(c->stream, q.image, c->img, s.chunk * 3, nbytes, -1);
     return launch_check(c, "p2p_sum_resolve");

@@ -82,10 +82,14 @@ struct PeerSet {
 };
 void launch_p2p_sync(hipStream_t s, uint32_t *my_flags, const PeerSet &peer_flags, int rank, int world, uint32_t seq,
                      uint32_t *status, unsigned long long timeout_ticks);
-void launch_p2p_depth_reduce(hipStream_t s, const PeerSet &depth, uint32_t *red, size_t first, size_t count, int world);
+constexpr int kP2POccBytes = 512;  // occupancy bitmap: one bit per screen tile (<= 4096)
+void launch_p2p_occupancy(hipStream_t s, const uint32_t *tile_start, int W, int H, uint32_t *occ);
+void launch_p2p_depth_reduce(hipStream_t s, const PeerSet &depth, const PeerSet &occ, uint32_t *red, size_t first,
+                             size_t count, int world, int W, int H);
 void launch_p2p_gather(hipStream_t s, const PeerSet &src, void *dst, size_t chunk_bytes, size_t nbytes,
                        int skip_owner);  // skip_owner < 0: copy every slice
-void launch_p2p_acc_resolve(hipStream_t s, const PeerSet &acc, uint8_t *img, size_t first, size_t count, int world);
+void launch_p2p_acc_resolve(hipStream_t s, const PeerSet &acc, const PeerSet &occ, uint8_t *img, size_t first,
+                            size_t count, int world, int W, int H);
 void launch_generate(hipStream_t s, int scene, uint64_t seed, uint64_t first, uint64_t count, uint64_t total,
                      float *x, float *y, float *z, uint32_t *rgba);
 void launch_aos_to_soa(hipStream_t s, const uint8_t *xyz, size_t xyz_stride, const uint8_t *rgb, size_t rgb_stride,

@@ -1597,27 +1597,64 @@ __global__ void k_p2p_sync(uint32_t *__restrict__ my_flags, PeerSet peer_flags, 
     }
 }
 
+// Tile occupancy: a rank whose binned frame has no entry in a screen tile has left that tile of
+// its depth buffer at the sentinel and of its accumulators at zero (rtr_clear), so nobody needs
+// to pull it.  Point slices of a spatially ordered cloud are spatially compact, hence most tiles
+// are occupied on one or two ranks only and the pulls shrink accordingly (exactly: MIN with the
+// sentinel and SUM with zero change nothing).  occ_r[t >> 5] bit (t & 31) = rank r has entries in
+// tile t; all ones when a rank's frame did not come from the bins.
+constexpr int kOccWords = 128;  // 4096 tiles
+
+__global__ void k_p2p_occupancy(const uint32_t *__restrict__ tile_start, int ntiles, uint32_t *__restrict__ occ) {
+    const int w = threadIdx.x;  // one 32-tile word per thread, kOccWords threads
+    uint32_t bits = 0;
+    for (int b = 0; b < 32; ++b) {
+        const int t = 32 * w + b;
+        if (tile_start == nullptr || (t < ntiles && tile_start[t + 1] > tile_start[t])) bits |= 1u << b;
+    }
+    occ[w] = bits;
+}
+
+// every rank's occupancy words into LDS (world x kOccWords dwords, one remote round trip per block)
+__device__ __forceinline__ void stage_occupancy(uint32_t *s_occ, const PeerSet &occ, int world) {
+    for (int i = threadIdx.x; i < world * kOccWords; i += kBlock)
+        s_occ[i] = static_cast<const uint32_t *>(occ.p[i / kOccWords])[i % kOccWords];
+    __syncthreads();
+}
+__device__ __forceinline__ bool occupied(const uint32_t *s_occ, int r, int tile) {
+    tile &= 32 * kOccWords - 1;  // frames beyond 4096 tiles never come from the bins: all ones anyway
+    return (s_occ[r * kOccWords + (tile >> 5)] >> (tile & 31)) & 1u;
+}
+
 // depth: red[first .. first + count) = MIN over ranks of depth_r[...] (u32 bit patterns, render.cu:81)
-__global__ __launch_bounds__(kBlock) void k_p2p_depth_reduce(PeerSet depth, uint32_t *__restrict__ red, size_t first,
-                                                             size_t count, int world) {
+__global__ __launch_bounds__(kBlock) void k_p2p_depth_reduce(PeerSet depth, PeerSet occ, uint32_t *__restrict__ red,
+                                                             size_t first, size_t count, int world, int W, TileGeom g) {
+    __shared__ uint32_t s_occ[kMaxPeers * kOccWords];
+    stage_occupancy(s_occ, occ, world);
     const size_t q = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 4;
     if (q >= count) return;
-    if (q + 4 <= count) {
-        uint4 m = *reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(depth.p[0]) + first + q);
-        for (int r = 1; r < world; ++r) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(depth.p[r]) + first + q);
+    if (q + 4 <= count && (W & 3) == 0) {  // the quad lies in one row and one tile
+        const size_t p = first + q;
+        const int tile = (int)((p / W) >> 5) * g.tiles_x + (int)((p % W) >> g.tw_shift);
+        uint4 m = make_uint4(RTR_EMPTY, RTR_EMPTY, RTR_EMPTY, RTR_EMPTY);
+        for (int r = 0; r < world; ++r) {
+            if (!occupied(s_occ, r, tile)) continue;
+            const uint4 v = *reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(depth.p[r]) + p);
             m.x = v.x < m.x ? v.x : m.x; m.y = v.y < m.y ? v.y : m.y;
             m.z = v.z < m.z ? v.z : m.z; m.w = v.w < m.w ? v.w : m.w;
         }
-        *reinterpret_cast<uint4 *>(red + first + q) = m;
+        *reinterpret_cast<uint4 *>(red + p) = m;
     } else {
-        for (size_t i = q; i < count; ++i) {
-            uint32_t m = static_cast<const uint32_t *>(depth.p[0])[first + i];
-            for (int r = 1; r < world; ++r) {
-                const uint32_t v = static_cast<const uint32_t *>(depth.p[r])[first + i];
+        for (size_t i = q; i < count && i < q + 4; ++i) {
+            const size_t p = first + i;
+            const int tile = (int)((p / W) >> 5) * g.tiles_x + (int)((p % W) >> g.tw_shift);
+            uint32_t m = RTR_EMPTY;
+            for (int r = 0; r < world; ++r) {
+                if (!occupied(s_occ, r, tile)) continue;
+                const uint32_t v = static_cast<const uint32_t *>(depth.p[r])[p];
                 m = v < m ? v : m;
             }
-            red[first + i] = m;
+            red[p] = m;
         }
     }
 }
@@ -1641,8 +1678,10 @@ __global__ void k_p2p_gather_tail(PeerSet src, uint8_t *__restrict__ dst, size_t
 
 // colour: img[first .. first + count) = resolve(SUM over ranks of acc_r[...]) (render.cu:125-128,147-162;
 // u32 sums wrap like the reference's atomicAdd).  first % 4 == 0; four pixels per thread.
-__global__ __launch_bounds__(kBlock) void k_p2p_acc_resolve(PeerSet acc, uint8_t *__restrict__ img, size_t first,
-                                                            size_t count, int world) {
+__global__ __launch_bounds__(kBlock) void k_p2p_acc_resolve(PeerSet acc, PeerSet occ, uint8_t *__restrict__ img,
+                                                            size_t first, size_t count, int world, int W, TileGeom g) {
+    __shared__ uint32_t s_occ[kMaxPeers * kOccWords];
+    stage_occupancy(s_occ, occ, world);
     const size_t q = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 4;
     if (q >= count) return;
     const int cnt = (count - q) < 4 ? (int)(count - q) : 4;
@@ -1650,11 +1689,15 @@ __global__ __launch_bounds__(kBlock) void k_p2p_acc_resolve(PeerSet acc, uint8_t
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         uint4 a = make_uint4(0, 0, 0, 0);
-        if (k < cnt)
+        if (k < cnt) {
+            const size_t p = first + q + k;
+            const int tile = (int)((p / W) >> 5) * g.tiles_x + (int)((p % W) >> g.tw_shift);
             for (int r = 0; r < world; ++r) {
-                const uint4 v = static_cast<const uint4 *>(acc.p[r])[first + q + k];
+                if (!occupied(s_occ, r, tile)) continue;
+                const uint4 v = static_cast<const uint4 *>(acc.p[r])[p];
                 a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
             }
+        }
         const uint32_t c = a.w;
         out[3 * k + 0] = c ? a.x / c : 0u;
         out[3 * k + 1] = c ? a.y / c : 0u;
@@ -1675,11 +1718,16 @@ void launch_p2p_sync(hipStream_t s, uint32_t *my_flags, const PeerSet &peer_flag
                      uint32_t *status, unsigned long long timeout_ticks) {
     hipLaunchKernelGGL(k_p2p_sync, dim3(1), dim3(64), 0, s, my_flags, peer_flags, rank, world, seq, status, timeout_ticks);
 }
-void launch_p2p_depth_reduce(hipStream_t s, const PeerSet &depth, uint32_t *red, size_t first, size_t count, int world) {
+// tile_start == NULL: every tile counts as occupied (the frame did not come from the bins)
+void launch_p2p_occupancy(hipStream_t s, const uint32_t *tile_start, int W, int H, uint32_t *occ) {
+    hipLaunchKernelGGL(k_p2p_occupancy, dim3(1), dim3(kOccWords), 0, s, tile_start, tile_count(W, H), occ);
+}
+void launch_p2p_depth_reduce(hipStream_t s, const PeerSet &depth, const PeerSet &occ, uint32_t *red, size_t first,
+                             size_t count, int world, int W, int H) {
     if (count == 0) return;
     const size_t quads = (count + 3) / 4;
-    hipLaunchKernelGGL(k_p2p_depth_reduce, dim3((unsigned)((quads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, depth, red,
-                       first, count, world);
+    hipLaunchKernelGGL(k_p2p_depth_reduce, dim3((unsigned)((quads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, depth, occ,
+                       red, first, count, world, W, tile_geom(W, H));
 }
 // gathers `nbytes` of a buffer cut into slices of `chunk_bytes` (a multiple of 16) owned by ranks 0, 1, ...
 void launch_p2p_gather(hipStream_t s, const PeerSet &src, void *dst, size_t chunk_bytes, size_t nbytes, int skip_owner) {
@@ -1693,11 +1741,12 @@ void launch_p2p_gather(hipStream_t s, const PeerSet &src, void *dst, size_t chun
             hipLaunchKernelGGL(k_p2p_gather_tail, dim3(1), dim3(64), 0, s, src, (uint8_t *)dst, n16 * 16, nbytes, owner, -1);
     }
 }
-void launch_p2p_acc_resolve(hipStream_t s, const PeerSet &acc, uint8_t *img, size_t first, size_t count, int world) {
+void launch_p2p_acc_resolve(hipStream_t s, const PeerSet &acc, const PeerSet &occ, uint8_t *img, size_t first,
+                            size_t count, int world, int W, int H) {
     if (count == 0) return;
     const size_t quads = (count + 3) / 4;
-    hipLaunchKernelGGL(k_p2p_acc_resolve, dim3((unsigned)((quads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, acc, img,
-                       first, count, world);
+    hipLaunchKernelGGL(k_p2p_acc_resolve, dim3((unsigned)((quads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, acc, occ, img,
+                       first, count, world, W, tile_geom(W, H));
 }
 
 // ---------------------------------------------------------------------------------

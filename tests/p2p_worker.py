@@ -16,17 +16,19 @@ import __graft_entry__ as entry  # noqa: E402
 
 def main():
     W, H, n, frames = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    scene, mode = sys.argv[5], int(sys.argv[6])
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     pkg, orc = entry.load_package(), entry.load_oracle()
     proj = pkg.Projector(0)
     lo, hi = pkg.shard_range(n, rank, world)
-    proj.generate_synthetic("room_shell", 11, lo, hi - lo, n)
+    proj.set_option("mode", mode)   # 0: the atomic form, no bins: every tile counts as occupied
+    proj.generate_synthetic(scene, 11, lo, hi - lo, n)
     proj.set_resolution(W, H)
     local = pkg.sharded.HipLocal(proj)
     local.bind_stream()
     sp = pkg.ShardedProjector(local, colour="reduce_scatter", exchange="p2p")
-    xyzw, rgba = orc.generate("room_shell", 11, 0, n, n)
+    xyzw, rgba = orc.generate(scene, 11, 0, n, n)
     ok, notes = True, []
     for k in range(frames):
         P = pkg.orbit_projection(7 * k, W, H)

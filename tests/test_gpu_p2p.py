@@ -24,11 +24,13 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("ranks,W,H", [(2, 640, 480), (3, 208, 120), (4, 1920, 1080), (3, 100, 50)])
-def test_p2p_exchange_matches_oracle(ranks, W, H):
+@pytest.mark.parametrize("ranks,W,H,scene,mode", [(2, 640, 480, "room_shell", 1), (3, 208, 120, "room_shell", 1),
+                                                   (4, 1920, 1080, "room_shell", 1), (3, 100, 50, "room_shell", 1),
+                                                   (3, 640, 480, "uniform_box", 1), (2, 208, 120, "room_shell", 0)])
+def test_p2p_exchange_matches_oracle(ranks, W, H, scene, mode):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "p2p_worker.py"), str(W), str(H),
-           "400000", "5"]
+           "400000", "5", scene, str(mode)]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-3000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("[")][-1]
