@@ -1173,6 +1173,12 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const float *__restrict__ hi,
     lo[idx] = min2(min2(a.x, a.y), min2(b.x, b.y));
 }
 
+// The reference tests `cur >= MAX_FLOAT` with MAX_FLOAT = 3.4028e38 (a double literal,
+// project_cloud.cu:21,97), i.e. in double precision.  0x7F7FFF8C is the smallest float whose value
+// is >= that literal, so the float comparison below is the same predicate for every float input
+// (NaN: false either way) without the f64 convert + compare.
+__device__ __forceinline__ bool at_max_float(float cur) { return cur >= __uint_as_float(0x7F7FFF8Cu); }
+
 // A pyramid level as the kernels below read it: in memory (row stride = its width) or as a
 // window of it staged in LDS.  w / h are the dims the reference's launch sequence uses for the
 // level (heights are the doubled TRUNCATED ones, project_cloud.cu:360-361).
@@ -1212,14 +1218,14 @@ __device__ __forceinline__ float lo_px(const Lv &lo, int x, int y) {
 // A10 compareImgsKernel (project_cloud.cu:88-126) for one hi-res pixel
 template <class Lv>
 __device__ __forceinline__ bool keep_px(const Lv &lo, float cur, int x, int y, float strength, float thr) {
-    if ((double)cur >= 3.4028e38) return false;  // MAX_FLOAT, project_cloud.cu:21,97
+    if (at_max_float(cur)) return false;  // MAX_FLOAT, project_cloud.cu:21,97
     const int lx = x >> 1, ly = y >> 1;
-    if (lap_flag(lo, lx, ly, thr)) {
+    if (lap_flag(lo, lx, ly, thr)) {  // only interior pixels can be flagged: the nine taps are in range
         bool keep = false;
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) keep = keep || (cur <= f_mul(lo_px(lo, lx + dx, ly + dy), strength));
+            for (int dx = -1; dx <= 1; ++dx) keep = keep | (cur <= f_mul(lo.at(lx + dx, ly + dy), strength));
         return keep;
     }
     return cur <= f_mul(lo_px(lo, lx, ly), strength);
@@ -1233,13 +1239,21 @@ template <class Lv>
 __device__ __forceinline__ uint32_t keep_quad(const Lv &lo, const float d[4], int x, int y, float strength, float thr) {
     const int lx = x >> 1, ly = y >> 1;
     float v[3][4], p[3][4];
+    if (lx >= 1 && lx + 2 < lo.w && ly >= 1 && ly + 1 < lo.h) {  // the whole 4x3 window is inside the level
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[j][i] = lo.at(lx - 1 + i, ly - 1 + j);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[j][i] = lo_px(lo, lx - 1 + i, ly - 1 + j);
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[j][i] = lo_px(lo, lx - 1 + i, ly - 1 + j);
-            p[j][i] = f_mul(v[j][i], strength);
-        }
+        for (int i = 0; i < 4; ++i) p[j][i] = f_mul(v[j][i], strength);
     uint32_t bits = 0;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -1266,7 +1280,7 @@ __device__ __forceinline__ uint32_t keep_quad(const Lv &lo, const float d[4], in
             for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int i = a; i < a + 3; ++i) any = any | (cur <= p[j][i]);
-            const bool keep = !((double)cur >= 3.4028e38) & (flag ? any : (cur <= p[1][a + 1]));
+            const bool keep = !at_max_float(cur) & (flag ? any : (cur <= p[1][a + 1]));
             bits |= keep ? (1u << k) : 0u;
         }
     }
@@ -1362,7 +1376,7 @@ __device__ __forceinline__ void final_quad(const Lv &l1, float4 d4, uint32_t iw0
         kbits = keep_quad(l1, d, x, y, strength, thr);
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) kbits |= !((double)d[k] >= 3.4028e38) ? (1u << k) : 0u;
+        for (int k = 0; k < 4; ++k) kbits |= !at_max_float(d[k]) ? (1u << k) : 0u;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
