@@ -57,6 +57,7 @@ typedef enum { RTR_SCENE_UNIFORM_BOX = 0, RTR_SCENE_ROOM_SHELL = 1 } rtr_scene;
 /* ---- 1. life cycle (ProjectCloud ctor/dtor, project_cloud.cu:189-266) ---------- */
 int rtr_abi_version(void);
 /* device: HIP ordinal of the GPU this context owns. */
+int rtr_device_count(void); /* HIP devices visible to this process (0 when there is none or HIP fails) */
 int rtr_create(rtr_ctx **out, int device);
 int rtr_destroy(rtr_ctx *ctx);
 const char *rtr_last_error(const rtr_ctx *ctx); /* ctx may be NULL: error of a failed rtr_create */

@@ -19,7 +19,7 @@ SYMBOLS = [
     "rtr_project_filtered", "rtr_render", "rtr_clear", "rtr_min_depth_pass", "rtr_accumulate_pass", "rtr_resolve",
     "rtr_filter", "rtr_device_buffer", "rtr_download_buffer", "rtr_timing_enable", "rtr_timing_reset",
     "rtr_timing_get", "rtr_set_option", "rtr_stream_probe", "rtr_resolve_range", "rtr_reorder_points", "rtr_reset_stream",
-    "rtr_p2p_export", "rtr_p2p_open", "rtr_p2p_close", "rtr_p2p_min_depth", "rtr_p2p_sum_resolve", "rtr_p2p_status",
+    "rtr_device_count", "rtr_p2p_export", "rtr_p2p_open", "rtr_p2p_close", "rtr_p2p_min_depth", "rtr_p2p_sum_resolve", "rtr_p2p_status",
 ]
 
 RTR_OK, RTR_ERR_INVALID, RTR_ERR_HIP, RTR_ERR_NO_OUTPUT, RTR_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
@@ -62,6 +62,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, u64, sz, i32 = C.c_void_p, C.c_uint64, C.c_size_t, C.c_int
     L.rtr_abi_version.restype = i32
+    L.rtr_device_count.argtypes = []
     L.rtr_create.argtypes = [C.POINTER(vp), i32]
     L.rtr_destroy.argtypes = [vp]
     L.rtr_last_error.argtypes = [vp]

@@ -339,6 +339,15 @@ void rtr_default_params(rtr_params *p) {
     p->levels = 4;                  // project_cloud.cu:23
 }
 
+int rtr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
 int rtr_create(rtr_ctx **out, int device) {
     if (!out) return fail(nullptr, RTR_ERR_INVALID, "out is NULL");
     *out = nullptr;

@@ -79,3 +79,16 @@ def test_p2p_single_rank_and_misuse(pkg, orc):
             p.p2p_sum_resolve()
     finally:
         p.close()
+
+
+def test_cpp_multi_process_example(pkg, tmp_path):
+    """examples/multi_gpu_p2p.cpp: the p2p exchange from plain C++ (fork, a shared page for the
+    handle blocks, no MPI / torch); every rank's frames must equal a single-context render."""
+    exe = str(tmp_path / "multi_gpu_p2p")
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "multi_gpu_p2p.cpp"), "-o", exe, pkg.LIB_PATH, "-lpthread",
+                           "-Wl,-rpath," + libdir])
+    res = subprocess.run([exe, "3", "900000", "640", "480", "6"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.startswith("ok: 3 ranks x 6 frames")
