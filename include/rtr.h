@@ -175,6 +175,9 @@ int rtr_p2p_open(rtr_ctx *ctx, int rank, int world, const rtr_p2p_handles *all /
 int rtr_p2p_close(rtr_ctx *ctx);
 int rtr_p2p_min_depth(rtr_ctx *ctx);
 int rtr_p2p_sum_resolve(rtr_ctx *ctx);
+/* The whole sharded frame in one call: rtr_clear, rtr_min_depth_pass, rtr_p2p_min_depth,
+ * rtr_accumulate_pass, rtr_p2p_sum_resolve and, if with_filter, rtr_filter. */
+int rtr_p2p_render(rtr_ctx *ctx, const float P[16], int with_filter);
 int rtr_p2p_status(rtr_ctx *ctx, uint32_t *barrier_timeouts);
 
 /* ---- 6. device-resident buffers (owned by the context, valid until the next

@@ -1079,6 +1079,23 @@ int rtr_p2p_sum_resolve(rtr_ctx *c) {
     return launch_check(c, "p2p_sum_resolve");
 }
 
+int rtr_p2p_render(rtr_ctx *c, const float P[16], int with_filter) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, P != nullptr, "P is NULL");
+    NEED(c, c->p2p.open, "rtr_p2p_open has not been called");
+    if (with_filter) {  // fail before any rank enters a barrier the others would wait in
+        DevGuard g(c->device);
+        if (int rc = ensure_pyramid(c)) return rc;
+    }
+    int rc = rtr_clear(c);
+    if (!rc) rc = rtr_min_depth_pass(c, P);
+    if (!rc) rc = rtr_p2p_min_depth(c);
+    if (!rc) rc = rtr_accumulate_pass(c, P);
+    if (!rc) rc = rtr_p2p_sum_resolve(c);
+    if (!rc && with_filter) rc = rtr_filter(c);
+    return rc;
+}
+
 // ---- buffers -----------------------------------------------------------------------
 
 int rtr_device_buffer(rtr_ctx *c, int which, void **ptr, size_t *bytes) {

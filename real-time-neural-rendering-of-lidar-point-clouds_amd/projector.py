@@ -203,6 +203,10 @@ class Projector:
     def p2p_sum_resolve(self):
         self._chk(self._lib.rtr_p2p_sum_resolve(self._ctx))
 
+    def p2p_render(self, P, with_filter=False):
+        P = self._P(P)
+        self._chk(self._lib.rtr_p2p_render(self._ctx, _vp(P), 1 if with_filter else 0))
+
     def p2p_timeouts(self):
         n = C.c_uint32()
         self._chk(self._lib.rtr_p2p_status(self._ctx, C.byref(n)))

@@ -110,6 +110,9 @@ class HipLocal:
     def p2p_sum_resolve(self):
         self.p.p2p_sum_resolve()
 
+    def p2p_render(self, P, with_filter):
+        self.p.p2p_render(P, with_filter)
+
     def p2p_timeouts(self):
         return self.p.p2p_timeouts()
 
@@ -197,7 +200,8 @@ class ShardedProjector:
                 return False
             self._p2p_verified = True
         else:
-            self._p2p_frame(P)
+            lo.p2p_render(P, with_filter)  # the whole sequence in one library call
+            return True
         if with_filter:
             lo.filter()
         return True
