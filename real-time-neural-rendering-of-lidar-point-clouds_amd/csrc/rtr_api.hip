@@ -79,6 +79,10 @@ struct rtr_ctx {
         uint32_t *flags = nullptr;        // [RTR_P2P_MAX_RANKS] uncached: barrier counters written by the peers
         uint32_t *occ = nullptr;          // [128] one bit per screen tile: this rank's frame has entries there
         bool occ_current = false;         // occ was computed from the bins that are valid now
+        bool occ_from_scan = false;       // ... by the scan kernel of this frame's tile sort (no separate launch)
+        bool whole_frame = false;         // inside rtr_p2p_render: the tile launches are the only writers of depth /
+                                          // accumulators (no clear, no read-modify-write) and T4<2> emits the pyramid
+        bool pyramid_done = false;
         bool acc_from_bins = false;       // the last accumulate pass used exactly those bins
         uint32_t *status_host = nullptr;  // mapped host word: barrier timeouts
         uint32_t *status_dev = nullptr;
@@ -738,6 +742,7 @@ static bool use_tiles(const rtr_ctx *c) {
 static int bin_points(rtr_ctx *c, const float P[16], bool overlapped = false) {
     c->list_valid = false;
     c->p2p.occ_current = false;
+    c->p2p.occ_from_scan = false;
     hipStream_t s1 = c->stream;
     if (overlapped) {
         c->cur ^= 1;
@@ -765,7 +770,8 @@ static int bin_points(rtr_ctx *c, const float P[16], bool overlapped = false) {
     }
     {
         Timed t(c, RTR_K_BIN);
-        rtr::launch_bin_sort(c->stream, cloud_of(c), c->W, c->H, c->F().lists, c->F().bins);
+        rtr::launch_bin_sort(c->stream, cloud_of(c), c->W, c->H, c->F().lists, c->F().bins, c->p2p.open ? c->p2p.occ : nullptr);
+        c->p2p.occ_from_scan = c->p2p.open;
     }
     memcpy(c->list_P, P, sizeof c->list_P);
     c->list_valid = true;
@@ -782,7 +788,7 @@ int rtr_min_depth_pass(rtr_ctx *c, const float P[16]) {
         if (int rc = bin_points(c, P)) return rc;
         Timed t(c, RTR_K_TILE);
         rtr::launch_tile(c->stream, 1, cloud_of(c), c->W, c->H, c->F().bins, c->prm.depth_window, c->depth, c->acc, c->img,
-                         0, nullptr);
+                         c->p2p.whole_frame ? 2 : 0, nullptr);
         mark_consumed(c);
     } else {
         Timed t(c, RTR_K_MIN_DEPTH);
@@ -800,10 +806,21 @@ int rtr_accumulate_pass(rtr_ctx *c, const float P[16]) {
     // the cloud like the reference does (render.cu:90-98)
     const bool use_bins = use_tiles(c) && c->list_valid && memcmp(c->list_P, P, sizeof c->list_P) == 0;
     c->p2p.acc_from_bins = use_bins && c->p2p.open && c->p2p.occ_current;
+    if (c->p2p.whole_frame && !use_bins) return fail(c, RTR_ERR_INVALID, "rtr_p2p_render: the bins are not valid");
     if (use_bins) {
+        // inside rtr_p2p_render with the default pyramid depth the tile kernel also emits the prefilter's
+        // levels and min / max partials from the GLOBAL depth tile it has just loaded
+        rtr::TilePyr pyr{};
+        pyr.enable = (c->p2p.whole_frame && c->p2p.pyramid_done) ? 1 : 0;
+        if (pyr.enable) {
+            pyr.L = c->lv;
+            pyr.n_eff_rows = (uint32_t)((c->H >> 4) << 4);
+            pyr.part_min = c->part_min;
+            pyr.part_max = c->part_max;
+        }
         Timed t(c, RTR_K_TILE);
         rtr::launch_tile(c->stream, 2, cloud_of(c), c->W, c->H, c->F().bins, c->prm.depth_window, c->depth, c->acc, c->img,
-                         1, nullptr);
+                         c->p2p.whole_frame ? 2 : 0, pyr.enable ? &pyr : nullptr);
         mark_consumed(c);
     } else {
         Timed t(c, RTR_K_ACCUMULATE);
@@ -1052,7 +1069,8 @@ int rtr_p2p_min_depth(rtr_ctx *c) {
     const size_t npix = (size_t)c->W * c->H;
     // which screen tiles this rank's frame touches at all (only known when it came from the bins)
     const bool binned = use_tiles(c) && c->list_valid;
-    rtr::launch_p2p_occupancy(c->stream, binned ? c->F().bins.tile_start : nullptr, c->W, c->H, q.occ);
+    if (!(binned && q.occ_from_scan))  // otherwise the scan kernel of the tile sort has already written it
+        rtr::launch_p2p_occupancy(c->stream, binned ? c->F().bins.tile_start : nullptr, c->W, c->H, q.occ);
     q.occ_current = binned;
     q.acc_from_bins = false;
     p2p_barrier(c);  // every rank's local depth (and occupancy) is complete
@@ -1087,12 +1105,20 @@ int rtr_p2p_render(rtr_ctx *c, const float P[16], int with_filter) {
         DevGuard g(c->device);
         if (int rc = ensure_pyramid(c)) return rc;
     }
-    int rc = rtr_clear(c);
+    // In the tile-binned form both tile launches of the frame visit every pixel, so they can be the
+    // only writers of the depth buffer / accumulators (no clear, no read-modify-write), and the
+    // accumulate launch -- which loads the GLOBAL depth tile -- can emit the prefilter's pyramid.
+    auto &q = c->p2p;
+    q.whole_frame = use_tiles(c);
+    q.pyramid_done = q.whole_frame && with_filter && c->prm.levels == 4;
+    int rc = q.whole_frame ? RTR_OK : rtr_clear(c);
     if (!rc) rc = rtr_min_depth_pass(c, P);
     if (!rc) rc = rtr_p2p_min_depth(c);
     if (!rc) rc = rtr_accumulate_pass(c, P);
     if (!rc) rc = rtr_p2p_sum_resolve(c);
-    if (!rc && with_filter) rc = rtr_filter(c);
+    const int parts = q.pyramid_done ? rtr::tile_count(c->W, c->H) : 0;
+    q.whole_frame = q.pyramid_done = false;
+    if (!rc && with_filter) rc = filter_impl(c, parts);
     return rc;
 }
 

@@ -67,7 +67,8 @@ void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int
                         uint32_t *tile_hist, uint32_t *blk_hist, const float *bounds);
 void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds);  // 6 floats per 256 points
 int reorder_morton(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, uint64_t n);  // rtr_reorder.hip
-void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const Lists &L, const Bins &B);
+// occ (optional): 128 words, one bit per tile that has entries (peer-to-peer exchange)
+void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const Lists &L, const Bins &B, uint32_t *occ = nullptr);
 void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const Bins &B, float window, uint32_t *depth,
                  uint32_t *acc, uint8_t *img, int write_acc, const TilePyr *pyr);
 void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *sink, int variant);

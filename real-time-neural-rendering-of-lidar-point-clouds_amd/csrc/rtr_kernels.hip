@@ -562,8 +562,12 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
 // histogram is re-zeroed for the next frame.  One workgroup of 1024 threads.
 __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *__restrict__ tile_hist, uint32_t *__restrict__ tile_start,
                                                     uint32_t *__restrict__ cursor, uint32_t *__restrict__ order,
-                                                    uint32_t *__restrict__ stats, int ntiles) {
+                                                    uint32_t *__restrict__ stats, int ntiles,
+                                                    uint32_t *__restrict__ occ) {
     __shared__ uint32_t s_w[16], s_m[16];
+    __shared__ uint32_t s_occ[128];  // tile occupancy bitmap for the peer-to-peer exchange (occ != NULL)
+    if (threadIdx.x < 128) s_occ[threadIdx.x] = 0;
+    __syncthreads();
     const int per = (ntiles + 1023) / 1024;  // <= 4 (ntiles <= 4096)
     const int lo = threadIdx.x * per;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -614,6 +618,12 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *__restrict__ tile_
             run += cnt[k];
         }
     if (threadIdx.x == 1023) tile_start[ntiles] = total;
+    if (occ) {
+        for (int k = 0; k < per && k < 4; ++k)
+            if (lo + k < ntiles && cnt[k]) atomicOr(&s_occ[(lo + k) >> 5], 1u << ((lo + k) & 31));
+        __syncthreads();
+        if (threadIdx.x < 128) occ[threadIdx.x] = s_occ[threadIdx.x];
+    }
     // frame statistics for the host (mapped host memory, read without synchronisation): total
     // entries and the entry count of the heaviest tile (one workgroup owns a whole tile in T4)
     if (threadIdx.x == 0 && stats) {
@@ -791,7 +801,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__
     const uint32_t e0 = tile_start[tile];
     uint32_t e1 = tile_start[tile + 1];
     const int dbg = write_acc >> 8;
-    write_acc &= 0xFF;
+    // MODE 1 / 2, bit 1: this launch is the only writer of the frame buffer (no rtr_clear before it):
+    // store the tile's depth / sums instead of folding them into what memory holds
+    const bool overwrite = (write_acc & 2) != 0;
+    write_acc &= 1;
     constexpr uint32_t T = kTileThreads;
 
     for (int p = tid; p < tpix; p += T) {
@@ -890,8 +903,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__
             if (inb) depth[gp] = s_depth[p];
         } else if (MODE == 1) {
             if (inb) {
-                uint32_t old = depth[gp], v = s_depth[p];
-                if (v < old) depth[gp] = v;
+                const uint32_t v = s_depth[p];
+                if (overwrite || v < depth[gp]) depth[gp] = v;
             }
         }
         if (MODE != 1) {
@@ -907,7 +920,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__
             }
             if (MODE == 2) {
                 if (inb) {
-                    uint4 o = reinterpret_cast<uint4 *>(acc)[gp];
+                    uint4 o = overwrite ? make_uint4(0u, 0u, 0u, 0u) : reinterpret_cast<uint4 *>(acc)[gp];
                     reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(o.x + a0, o.y + a1, o.z + a2, o.w + c);
                 }
             } else {
@@ -938,6 +951,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__
         }
         if (pyr.enable)  // s_acc is free now (the colours were resolved into s_rgb before the barrier)
             tile_pyramid(s_depth, s_acc, g, tx0, ty0, pyr.L, pyr.n_eff_rows, pyr.part_min, pyr.part_max, tile, tid, T);
+    }
+    if (MODE == 2 && pyr.enable) {  // sharded frames: s_depth holds the GLOBAL minimum of the tile here
+        __syncthreads();            // the sums have been read out of s_acc
+        tile_pyramid(s_depth, s_acc, g, tx0, ty0, pyr.L, pyr.n_eff_rows, pyr.part_min, pyr.part_max, tile, tid, T);
     }
 }
 
@@ -1000,11 +1017,11 @@ void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds) {
                        (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, bounds);
 }
 
-void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const Lists &L, const Bins &B) {
+void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const Lists &L, const Bins &B, uint32_t *occ) {
     TileGeom g = tile_geom(W, H);
     uint64_t n4 = (c.n + 3) / 4;
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, B.tile_hist, B.tile_start, B.cursor, B.order, B.stats,
-                       g.ntiles);
+                       g.ntiles, occ);
     if (n4 == 0) return;
     hipLaunchKernelGGL(k_scatter<kScatterWPR>, dim3(point_grid(n4, c.grid)), dim3(kBlock * kScatterWPR),
                        g.ntiles * sizeof(uint32_t), s, L, g.ntiles, g.tw_shift + 5, B.blk_hist, B.cursor, B.entries,
@@ -1025,11 +1042,11 @@ void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const Bi
     else if (mode == 1)
         hipLaunchKernelGGL(k_tile<1>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, B.order, c.rgba, g,
                            W,
-                           H, window, depth, acc, img, 0, none);
-    else
+                           H, window, depth, acc, img, write_acc & 2, none);
+    else  // mode 2 always writes the accumulators; bit 1 of write_acc = overwrite; pyr: also emit the pyramid
         hipLaunchKernelGGL(k_tile<2>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, B.order, c.rgba, g,
                            W,
-                           H, window, depth, acc, img, 1, none);
+                           H, window, depth, acc, img, 1 | (write_acc & 2), pyr ? *pyr : none);
 }
 
 // ---------------------------------------------------------------------------------

@@ -168,12 +168,7 @@ class ShardedProjector:
             pass
 
     def _p2p_frame(self, P):
-        lo = self.local
-        lo.clear()
-        lo.min_depth_pass(P)
-        lo.p2p_min_depth()
-        lo.accumulate_pass(P)
-        lo.p2p_sum_resolve()
+        self.local.p2p_render(P, False)  # the same library call the later frames use
 
     def _render_p2p(self, P, with_filter):
         """-> False if the p2p form is (now) unavailable and the collectives must render the frame."""
