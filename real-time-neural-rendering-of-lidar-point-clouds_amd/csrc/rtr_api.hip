@@ -83,6 +83,8 @@ struct rtr_ctx {
         bool whole_frame = false;         // inside rtr_p2p_render: the tile launches are the only writers of depth /
                                           // accumulators (no clear, no read-modify-write) and T4<2> emits the pyramid
         bool pyramid_done = false;
+        bool depth_sliced = false;        // ... RTR_BUF_DEPTH is completed by the accumulate launch (no depth gather)
+        bool image_sliced = false;        // ... the prefilter reads the image from the ranks' slices (no image gather)
         bool acc_from_bins = false;       // the last accumulate pass used exactly those bins
         uint32_t *status_host = nullptr;  // mapped host word: barrier timeouts
         uint32_t *status_dev = nullptr;
@@ -154,6 +156,16 @@ void p2p_release(rtr_ctx *c) {  // the peers' mappings and this rank's exchange 
     q.seq = 0;
 }
 
+struct Slice { size_t chunk, first, count; };
+Slice p2p_slice(const rtr_ctx *c) {  // pixels owned by this rank: slices are multiples of 16 pixels
+    const size_t npix = (size_t)c->W * c->H, w = (size_t)c->p2p.world;
+    Slice s;
+    s.chunk = (((npix + w - 1) / w) + 15) & ~(size_t)15;  // 16 pixels: 64 B of depth, 48 B of image
+    s.first = s.chunk * (size_t)c->p2p.rank;
+    if (s.first > npix) s.first = npix;
+    s.count = (npix - s.first) < s.chunk ? npix - s.first : s.chunk;
+    return s;
+}
 void free_frame(rtr_ctx *c) {
     c->list_valid = false;
     p2p_release(c);
@@ -818,9 +830,15 @@ int rtr_accumulate_pass(rtr_ctx *c, const float P[16]) {
             pyr.part_min = c->part_min;
             pyr.part_max = c->part_max;
         }
+        rtr::Sliced dsl{};
+        if (c->p2p.whole_frame && c->p2p.depth_sliced) {
+            dsl.src = c->p2p.reduced;
+            dsl.chunk = p2p_slice(c).chunk;
+        }
+        c->p2p.depth_sliced = false;
         Timed t(c, RTR_K_TILE);
         rtr::launch_tile(c->stream, 2, cloud_of(c), c->W, c->H, c->F().bins, c->prm.depth_window, c->depth, c->acc, c->img,
-                         c->p2p.whole_frame ? 2 : 0, pyr.enable ? &pyr : nullptr);
+                         c->p2p.whole_frame ? 2 : 0, pyr.enable ? &pyr : nullptr, dsl.chunk ? &dsl : nullptr);
         mark_consumed(c);
     } else {
         Timed t(c, RTR_K_ACCUMULATE);
@@ -849,14 +867,14 @@ int rtr_resolve_range(rtr_ctx *c, const void *acc_dev, uint64_t first_pixel, uin
     return launch_check(c, "resolve_range");
 }
 
-static int filter_impl(rtr_ctx *c, int pyramid_parts) {
+static int filter_impl(rtr_ctx *c, int pyramid_parts, const rtr::Sliced *img_slices = nullptr) {
     if (int rc = check_frame(c)) return rc;
     DevGuard g(c->device);
     if (int rc = ensure_pyramid(c)) return rc;
     {
         Timed t(c, RTR_K_FILTER);
         rtr::launch_filter(c->stream, c->lv, c->depth, c->img, c->mask, c->tensor, c->minmax, c->part_min, c->part_max,
-                           c->W, c->H, c->prm.filter_strength, c->prm.gradient_threshold, pyramid_parts);
+                           c->W, c->H, c->prm.filter_strength, c->prm.gradient_threshold, pyramid_parts, img_slices);
     }
     return launch_check(c, "filter");
 }
@@ -1043,16 +1061,6 @@ int rtr_p2p_status(rtr_ctx *c, uint32_t *barrier_timeouts) {
 
 namespace {
 constexpr unsigned long long kP2PTimeoutTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
-struct Slice { size_t chunk, first, count; };
-Slice p2p_slice(const rtr_ctx *c) {  // pixels owned by this rank: slices are multiples of 16 pixels
-    const size_t npix = (size_t)c->W * c->H, w = (size_t)c->p2p.world;
-    Slice s;
-    s.chunk = (((npix + w - 1) / w) + 15) & ~(size_t)15;  // 16 pixels: 64 B of depth, 48 B of image
-    s.first = s.chunk * (size_t)c->p2p.rank;
-    if (s.first > npix) s.first = npix;
-    s.count = (npix - s.first) < s.chunk ? npix - s.first : s.chunk;
-    return s;
-}
 void p2p_barrier(rtr_ctx *c) {
     auto &q = c->p2p;
     rtr::launch_p2p_sync(c->stream, q.flags, q.flags_of, q.rank, q.world, ++q.seq, q.status_dev, kP2PTimeoutTicks);
@@ -1076,7 +1084,10 @@ int rtr_p2p_min_depth(rtr_ctx *c) {
     p2p_barrier(c);  // every rank's local depth (and occupancy) is complete
     rtr::launch_p2p_depth_reduce(c->stream, q.depth, q.occ_of, q.red, s.first, s.count, q.world, c->W, c->H);
     p2p_barrier(c);  // every slice is reduced; nobody reads the local depth buffers any more
-    rtr::launch_p2p_gather(c->stream, q.reduced, c->depth, s.chunk * 4, npix * 4, -1);
+    if (q.whole_frame)
+        q.depth_sliced = true;  // the accumulate launch reads the slices tile by tile and stores the result
+    else
+        rtr::launch_p2p_gather(c->stream, q.reduced, c->depth, s.chunk * 4, npix * 4, -1);
     return launch_check(c, "p2p_min_depth");
 }
 
@@ -1093,7 +1104,10 @@ int rtr_p2p_sum_resolve(rtr_ctx *c) {
     p2p_barrier(c);  // every rank's accumulators are complete (and its reduced-depth slice has been read)
     rtr::launch_p2p_acc_resolve(c->stream, q.accum, q.occ_of, q.ximg, s.first, s.count, q.world, c->W, c->H);
     p2p_barrier(c);  // every image slice is resolved; nobody reads the accumulators any more
-    rtr::launch_p2p_gather(c->stream, q.image, c->img, s.chunk * 3, nbytes, -1);
+    if (q.whole_frame && q.pyramid_done)
+        q.image_sliced = true;  // the fused prefilter reads the slices itself and writes RTR_BUF_IMAGE
+    else
+        rtr::launch_p2p_gather(c->stream, q.image, c->img, s.chunk * 3, nbytes, -1);
     return launch_check(c, "p2p_sum_resolve");
 }
 
@@ -1117,8 +1131,13 @@ int rtr_p2p_render(rtr_ctx *c, const float P[16], int with_filter) {
     if (!rc) rc = rtr_accumulate_pass(c, P);
     if (!rc) rc = rtr_p2p_sum_resolve(c);
     const int parts = q.pyramid_done ? rtr::tile_count(c->W, c->H) : 0;
-    q.whole_frame = q.pyramid_done = false;
-    if (!rc && with_filter) rc = filter_impl(c, parts);
+    rtr::Sliced isl{};
+    if (q.image_sliced) {
+        isl.src = q.image;
+        isl.chunk = p2p_slice(c).chunk;
+    }
+    q.whole_frame = q.pyramid_done = q.depth_sliced = q.image_sliced = false;
+    if (!rc && with_filter) rc = filter_impl(c, parts, isl.chunk ? &isl : nullptr);
     return rc;
 }
 

@@ -34,6 +34,18 @@ struct Lists {
     uint32_t *counts;               // [num_waves]
     uint64_t region_cap;
 };
+// peer-to-peer exchange (see the comment on k_p2p_sync): p[r] = rank r's buffer as mapped into this process
+constexpr int kMaxPeers = 16;
+struct PeerSet {
+    void *p[kMaxPeers];
+};
+// A frame-sized buffer that still lies in per-rank slices of `chunk` elements (the reduced depth /
+// the resolved image right after the slice kernels): element i is read from src.p[i / chunk].
+// chunk == 0: not sliced, use the local buffer.
+struct Sliced {
+    PeerSet src;
+    size_t chunk;
+};
 struct TilePyr {  // F1 folded into T4 (whole-frame calls with the default 4 levels)
     FilterLevels L;
     uint32_t n_eff_rows;
@@ -69,18 +81,15 @@ void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds);  // 6 fl
 int reorder_morton(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, uint64_t n);  // rtr_reorder.hip
 // occ (optional): 128 words, one bit per tile that has entries (peer-to-peer exchange)
 void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const Lists &L, const Bins &B, uint32_t *occ = nullptr);
+// depth_slices (mode 2 only): read the global depth from the ranks' reduced slices and store it to `depth`
 void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const Bins &B, float window, uint32_t *depth,
-                 uint32_t *acc, uint8_t *img, int write_acc, const TilePyr *pyr);
+                 uint32_t *acc, uint8_t *img, int write_acc, const TilePyr *pyr, const Sliced *depth_slices = nullptr);
 void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *sink, int variant);
 void launch_resolve(hipStream_t s, const uint32_t *acc, uint8_t *img, size_t npix);
+// img_slices (4 levels only): read the input image from the ranks' resolved slices (chunk in pixels)
 void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, uint8_t *img, uint8_t *mask,
                    uint16_t *tensor, uint32_t *minmax, uint32_t *part_min, uint32_t *part_max, int W, int H,
-                   float strength, float thr, int pyramid_parts);
-// peer-to-peer exchange (see the comment on k_p2p_sync): p[r] = rank r's buffer as mapped into this process
-constexpr int kMaxPeers = 16;
-struct PeerSet {
-    void *p[kMaxPeers];
-};
+                   float strength, float thr, int pyramid_parts, const Sliced *img_slices = nullptr);
 void launch_p2p_sync(hipStream_t s, uint32_t *my_flags, const PeerSet &peer_flags, int rank, int world, uint32_t seq,
                      uint32_t *status, unsigned long long timeout_ticks);
 constexpr int kP2POccBytes = 512;  // occupancy bitmap: one bit per screen tile (<= 4096)

@@ -789,7 +789,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__
                                                         const uint32_t *__restrict__ rgba, TileGeom g, int W, int H,
                                                         float window, uint32_t *__restrict__ depth,
                                                         uint32_t *__restrict__ acc, uint8_t *__restrict__ img,
-                                                        int write_acc, TilePyr pyr) {
+                                                        int write_acc, TilePyr pyr, Sliced dsl) {
     extern __shared__ uint32_t s_mem[];
     const int tpix = 32 << g.tw_shift;  // pixels per tile
     uint32_t *s_depth = s_mem;          // [tpix]
@@ -810,7 +810,18 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__
     for (int p = tid; p < tpix; p += T) {
         if (MODE == 2) {
             int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
-            s_depth[p] = (x < W && y < H) ? depth[(size_t)y * W + x] : RTR_EMPTY;
+            if (x < W && y < H) {
+                const size_t gp = (size_t)y * W + x;
+                if (dsl.chunk) {  // sharded frame: the global minimum still lies in the ranks' reduced slices
+                    const uint32_t v = static_cast<const uint32_t *>(dsl.src.p[gp / dsl.chunk])[gp];
+                    s_depth[p] = v;
+                    depth[gp] = v;  // ... and this launch is what completes RTR_BUF_DEPTH
+                } else {
+                    s_depth[p] = depth[gp];
+                }
+            } else {
+                s_depth[p] = RTR_EMPTY;
+            }
         } else {
             s_depth[p] = RTR_EMPTY;
         }
@@ -1029,8 +1040,10 @@ void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const Lists &L
 }
 
 void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const Bins &B, float window, uint32_t *depth,
-                 uint32_t *acc, uint8_t *img, int write_acc, const TilePyr *pyr) {
+                 uint32_t *acc, uint8_t *img, int write_acc, const TilePyr *pyr, const Sliced *depth_slices) {
     TileGeom g = tile_geom(W, H);
+    Sliced nosl{};
+    nosl.chunk = 0;
     size_t tpix = (size_t)32 << g.tw_shift;
     size_t lds = (mode == 1 ? tpix : 5 * tpix) * sizeof(uint32_t) + (mode == 0 ? 3 * tpix : 0);
     TilePyr none{};
@@ -1038,15 +1051,15 @@ void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const Bi
     if (mode == 0)
         hipLaunchKernelGGL(k_tile<0>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, B.order, c.rgba, g,
                            W,
-                           H, window, depth, acc, img, write_acc | ((c.debug >> 2) << 10), pyr ? *pyr : none);
+                           H, window, depth, acc, img, write_acc | ((c.debug >> 2) << 10), pyr ? *pyr : none, nosl);
     else if (mode == 1)
         hipLaunchKernelGGL(k_tile<1>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, B.order, c.rgba, g,
                            W,
-                           H, window, depth, acc, img, write_acc & 2, none);
+                           H, window, depth, acc, img, write_acc & 2, none, nosl);
     else  // mode 2 always writes the accumulators; bit 1 of write_acc = overwrite; pyr: also emit the pyramid
         hipLaunchKernelGGL(k_tile<2>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, B.order, c.rgba, g,
                            W,
-                           H, window, depth, acc, img, 1 | (write_acc & 2), pyr ? *pyr : none);
+                           H, window, depth, acc, img, 1 | (write_acc & 2), pyr ? *pyr : none, depth_slices ? *depth_slices : nosl);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1490,7 +1503,7 @@ __global__ __launch_bounds__(kBlock) void k_filter4(const float *__restrict__ g1
                                                     const uint32_t *__restrict__ part_min,
                                                     const uint32_t *__restrict__ part_max, int nparts,
                                                     uint32_t *__restrict__ minmax, int W, int H, int blocks_x,
-                                                    float strength, float thr) {
+                                                    float strength, float thr, Sliced isl) {
     __shared__ float s1[kF1x * kF1y], s2[kF2x * kF2y], s3[kF3x * kF3y], s4[kF4x * kF4y];
     __shared__ uint32_t s_mm[8];
     __shared__ uint16_t s_lut[256];  // colour byte -> fp16 bits: one IEEE division per thread instead of twelve
@@ -1505,7 +1518,9 @@ __global__ __launch_bounds__(kBlock) void k_filter4(const float *__restrict__ g1
     uint32_t iw0 = 0, iw1 = 0, iw2 = 0;
     if (inb) {
         d4 = *reinterpret_cast<const float4 *>(depth + idx);
-        const uint32_t *ip = reinterpret_cast<const uint32_t *>(img + idx * 3);
+        // sharded frame: the resolved image still lies in the ranks' slices (16-pixel multiples: a quad has one owner)
+        const uint8_t *src = isl.chunk ? static_cast<const uint8_t *>(isl.src.p[idx / isl.chunk]) : img;
+        const uint32_t *ip = reinterpret_cast<const uint32_t *>(src + idx * 3);
         iw0 = ip[0]; iw1 = ip[1]; iw2 = ip[2];
     }
     // A12: every workgroup folds the per-tile min / max partials itself (a few KB out of L2, in
@@ -1558,7 +1573,7 @@ __global__ __launch_bounds__(kBlock) void k_filter4(const float *__restrict__ g1
 // A14 applyDepthFilter (project_cloud.cu:331-392)
 void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, uint8_t *img, uint8_t *mask,
                    uint16_t *tensor, uint32_t *minmax, uint32_t *part_min, uint32_t *part_max, int W, int H,
-                   float strength, float thr, int pyramid_parts) {
+                   float strength, float thr, int pyramid_parts, const Sliced *img_slices) {
     auto blocks = [](size_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); };
     const int nl = L.levels;
     const int h_eff = (H >> nl) << nl;
@@ -1570,7 +1585,8 @@ void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, u
         const int bx = (W + kFuseW - 1) / kFuseW, by = (H + kFuseH - 1) / kFuseH;
         hipLaunchKernelGGL(k_filter4, dim3(bx * by), dim3(kBlock), 0, s, L.lv[1], L.lv[2], L.lv[3], L.lv[4], L.h[4],
                            (float *)depth_bits, img, mask, tensor, part_min, part_max,
-                           pyramid_parts > 0 ? pyramid_parts : nparts, minmax, W, H, bx, strength, thr);
+                           pyramid_parts > 0 ? pyramid_parts : nparts, minmax, W, H, bx, strength, thr,
+                           img_slices ? *img_slices : Sliced{});
         return;
     }
     {
