@@ -65,11 +65,15 @@ void rtr_default_params(rtr_params *p);
 int rtr_set_params(rtr_ctx *ctx, const rtr_params *p);
 int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
 /* Tuning knobs that never change the frame.
- *  "mode": 1 (default) tile-binned -- the cloud is streamed ONCE, in-frustum points are
- *          counting-sorted by 32-row screen tile and a per-tile LDS z-buffer does min +
- *          accumulate + resolve (no global atomics on the frame buffers); 0 = the
- *          reference's structure: two full passes with atomicMin / atomicAdd
+ *  "mode": 1 (default) tile-binned -- the cloud is streamed ONCE, every in-frustum point is
+ *          appended as one 8-byte entry to the stream of its screen tile and a per-tile LDS
+ *          z-buffer does min + accumulate + resolve (no global atomics on the frame buffers);
+ *          0 = the reference's structure: two full passes with atomicMin / atomicAdd
  *          (render.cu:53-130).
+ *  "split_threshold" (default 32768; 0 = never), "split_slice" (default 16384): a screen tile
+ *          holding more entries than the threshold is processed by several workgroups, each
+ *          taking a slice of at least split_slice entries (a distant overview that packs the
+ *          whole cloud into a few tiles would otherwise serialise on them).
  *  "auto_reorder": 1 = every later rtr_upload_points / rtr_generate_synthetic is followed by
  *          rtr_reorder_points, best effort (skipped when the sort's scratch does not fit).  Default 0
  *          here; the drop-in classes (rtr::ProjectCloud, the Python mirror) switch it on: the
@@ -86,10 +90,8 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          on MI355X the gain is 0-3 % ("Overlap").  "tail_cus" = t (0..31, set
  *          before "overlap") additionally gives the two streams disjoint CU masks, t CUs of every
  *          XCD for the tail.
- *  "point_grid": workgroups of the grid-stride point kernels (default 1024 = 4 per CU; the
- *          wave lists are sized for it, so changing it re-allocates them).
- *  "debug_skip", "probe_variant": measurement aids of tools/kbench.py and tools/probe_variants.py
- *          (attribute kernel time by switching phases off: frames are WRONG while debug_skip != 0). */
+ *  "point_grid": workgroups of the grid-stride point kernels (default 1024 = 4 per CU).
+ *  "probe_variant": measurement aid of tools/probe_variants.py (selects the rtr_stream_probe kernel). */
 int rtr_set_option(rtr_ctx *ctx, const char *key, int value);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's
  * own non-blocking stream; NULL means HIP's default stream.  rtr_reset_stream returns to the
@@ -199,8 +201,9 @@ typedef enum {
     RTR_K_CLEAR = 0, RTR_K_MIN_DEPTH = 1, RTR_K_ACCUMULATE = 2, RTR_K_RESOLVE = 3, RTR_K_FILTER = 4,
     RTR_K_PROBE = 5, RTR_K_TILE = 6, RTR_K_BIN = 7, RTR_K_COUNT = 8
 } rtr_kernel_id;
-/* mode 1: RTR_K_MIN_DEPTH = streaming projection + candidate lists (T1), RTR_K_BIN = scan +
- * counting sort by tile (T2-T3), RTR_K_TILE = per-tile z-buffer (T4); RTR_K_CLEAR / ACCUMULATE / RESOLVE are then only used by the phase calls. */
+/* mode 1: RTR_K_MIN_DEPTH = streaming projection + append to the tile streams (T1), RTR_K_TILE =
+ * per-tile z-buffer (T4); RTR_K_BIN is unused since the tile sort was removed (kept for ABI
+ * stability); RTR_K_CLEAR / ACCUMULATE / RESOLVE are then only used by the phase calls. */
 /* Read-only probe: same loads and projection arithmetic as the point passes, no frame-
  * buffer traffic -- measures the streaming ceiling of the access pattern. */
 int rtr_stream_probe(rtr_ctx *ctx, const float P[16]);
@@ -210,6 +213,10 @@ int rtr_stream_probe(rtr_ctx *ctx, const float P[16]);
  * time, 3 % of a frame); 0: off.  rtr_timing_get synchronises and returns the accumulated device
  * time and the number of bracketed launches. */
 int rtr_timing_enable(rtr_ctx *ctx, int on);
+/* Statistics of the last binned frame (mode 1; synchronises the stream): out[0] work items of the
+ * tile kernel, [1] of them slices of split tiles, [2] in-frustum entries, [3] entries of the
+ * heaviest tile, [4] slice size used, [5] error bits (0 = none), [6] split tiles, [7] reserved. */
+int rtr_frame_stats(rtr_ctx *ctx, uint32_t out[8]);
 int rtr_timing_reset(rtr_ctx *ctx);
 int rtr_timing_get(rtr_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);
 

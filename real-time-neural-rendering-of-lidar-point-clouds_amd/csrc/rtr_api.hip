@@ -40,15 +40,13 @@ struct rtr_ctx {
     rtr::FilterLevels lv{};
     int lv_levels = 0;  // levels the pyramid was allocated for
 
-    // tile-binned pipeline: wave-private candidate lists (T1) and their tile-sorted copy (T3)
+    // tile-binned pipeline: the tile store T1 appends to and T4 reads (rtr_kernels.h)
     // (two sets: with option "overlap" T1 of frame k+1 fills one set on the front stream while the
     // tail of frame k still reads the other)
     struct FrontSet {
-        rtr::Lists lists{};
-        rtr::Bins bins{};
-        uint64_t list_n = 0;        // point count the list / bin buffers were sized for
-        int tiles_n = 0;            // tile count the histogram buffers were sized for
-        size_t blk_hist_n = 0;      // elements blk_hist was sized for
+        rtr::TileStore store{};
+        uint64_t pool_n = 0;        // point count the dynamic extent pool was sized for
+        int nst = 0, ntiles = 0;    // tile counts the per-tile arrays were sized for
         hipEvent_t binned = nullptr, consumed = nullptr;  // T1 done (front stream) / T4 done (tail stream)
         bool consumed_valid = false;
     } fs[2];
@@ -63,14 +61,13 @@ struct rtr_ctx {
     int opt_mode = 1;           // 0 = two-pass global atomics (the reference's structure),
                                 // 1 = tile-binned LDS z-buffer (default)
     int opt_keep_accum = 0;     // whole-frame calls also materialise RTR_BUF_ACCUM
-    uint32_t *stats_host = nullptr;  // mapped host memory written by the scan kernel: {entries, heaviest tile}
-    uint32_t atomic_frames = 0;      // consecutive whole frames rendered in the atomic form because of a hot tile
-    bool force_atomic = false;       // set around such a frame
+    bool force_atomic = false;       // set around a whole frame that takes the atomic form (> 4096 tiles)
+    int opt_heavy = 32768;           // tiles with more entries are split over several workgroups in T4 ...
+    int opt_slice = 16384;           // ... into slices of at least this many entries
     int opt_probe = 0;          // rtr_stream_probe variant (experiments)
     int opt_cull = 0;           // per-chunk frustum culling in T1
     int opt_auto_reorder = 0;   // Morton-sort every cloud right after upload / generation
     int opt_grid = rtr::kDefaultPointGrid;  // workgroups of the point kernels
-    int opt_debug = 0;          // timing experiments (frames become wrong)
 
     // peer-to-peer exchange (rtr_p2p_*): own exchange buffers, the peers' mappings, barrier state
     struct P2P {
@@ -79,7 +76,7 @@ struct rtr_ctx {
         uint32_t *flags = nullptr;        // [RTR_P2P_MAX_RANKS] uncached: barrier counters written by the peers
         uint32_t *occ = nullptr;          // [128] one bit per screen tile: this rank's frame has entries there
         bool occ_current = false;         // occ was computed from the bins that are valid now
-        bool occ_from_scan = false;       // ... by the scan kernel of this frame's tile sort (no separate launch)
+        bool occ_from_scan = false;       // ... by the epilogue of this frame's T1 (no separate launch)
         bool whole_frame = false;         // inside rtr_p2p_render: the tile launches are the only writers of depth /
                                           // accumulators (no clear, no read-modify-write) and T4<2> emits the pyramid
         bool pyramid_done = false;
@@ -130,8 +127,15 @@ static int fail(rtr_ctx *c, int code, const char *fmt, ...) {
 
 namespace {
 
-struct DevGuard {  // contexts pin their device for the duration of a call
-    explicit DevGuard(int dev) { (void)hipSetDevice(dev); }
+struct DevGuard {  // contexts pin their device for the duration of a call and hand the caller's back
+    int prev = -1;
+    explicit DevGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev); else prev = -1;
+    }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DevGuard(const DevGuard &) = delete;
+    DevGuard &operator=(const DevGuard &) = delete;
 };
 
 template <class T>
@@ -172,19 +176,21 @@ void free_frame(rtr_ctx *c) {
     dfree(c->depth); dfree(c->acc); dfree(c->img); dfree(c->mask); dfree(c->part_min); dfree(c->part_max); dfree(c->tensor);
     for (int i = 1; i <= 8; ++i) dfree(c->lv.lv[i]);
     for (auto &f : c->fs) {
-        dfree(f.bins.tile_hist); dfree(f.bins.tile_start); dfree(f.bins.cursor); dfree(f.bins.order); dfree(f.bins.blk_hist);
-        f.tiles_n = 0; f.blk_hist_n = 0;
+        auto &t = f.store;
+        dfree(t.ext0); dfree(t.dir); dfree(t.fill); dfree(t.count); dfree(t.tile_cnt); dfree(t.items); dfree(t.hdr);
+        dfree(t.hctr); dfree(t.ticket); dfree(t.pool_next);
+        f.nst = f.ntiles = 0;
     }
     c->lv.lv[0] = nullptr;
     c->W = c->H = 0;
     c->lv_levels = 0;
 }
 
-void free_lists(rtr_ctx *c) {
+void free_lists(rtr_ctx *c) {  // the dynamic extent pools (sized by the point count)
     for (auto &f : c->fs) {
-        dfree(f.lists.tiled); dfree(f.lists.depth); dfree(f.lists.idx); dfree(f.lists.counts);
-        dfree(f.bins.entries);
-        f.list_n = 0;
+        dfree(f.store.dyn);
+        f.store.dyn_cap = 0;
+        f.pool_n = 0;
     }
     c->list_valid = false;
 }
@@ -195,38 +201,53 @@ void free_cloud(rtr_ctx *c) {
     c->n = c->cap = 0;
 }
 
-int ensure_tiles(rtr_ctx *c, hipStream_t s) {  // s: the stream T1 will run on
-    int nt = rtr::tile_count(c->W, c->H);
-    if (c->F().bins.tile_hist && c->F().tiles_n == nt) return RTR_OK;
-    dfree(c->F().bins.tile_hist); dfree(c->F().bins.tile_start); dfree(c->F().bins.cursor); dfree(c->F().bins.order);
-    HIP_TRY(c, hipMalloc((void **)&c->F().bins.tile_hist, (size_t)nt * 4));
-    HIP_TRY(c, hipMalloc((void **)&c->F().bins.tile_start, (size_t)(nt + 1) * 4));
-    HIP_TRY(c, hipMalloc((void **)&c->F().bins.cursor, (size_t)nt * 4));
-    HIP_TRY(c, hipMalloc((void **)&c->F().bins.order, (size_t)nt * 4));
-    HIP_TRY(c, hipMemsetAsync(c->F().bins.tile_hist, 0, (size_t)nt * 4, s));
-    c->F().tiles_n = nt;
+// Per-resolution part of the tile store: a static 32 KB extent, a stream length, an extent directory
+// per 32x16 storage tile, and the tile kernel's work list.  s: the stream T1 will run on.
+int ensure_tiles(rtr_ctx *c, hipStream_t s) {
+    const int nt = rtr::tile_count(c->W, c->H), nst = rtr::storage_tile_count(c->W, c->H);
+    auto &f = c->F();
+    auto &t = f.store;
+    if (t.ext0 && f.nst == nst && f.ntiles == nt) return RTR_OK;
+    dfree(t.ext0); dfree(t.dir); dfree(t.fill); dfree(t.count); dfree(t.tile_cnt); dfree(t.items); dfree(t.hdr);
+    dfree(t.hctr); dfree(t.ticket); dfree(t.pool_next);
+    f.nst = f.ntiles = 0;
+    c->list_valid = false;
+    const size_t dir_bytes = (size_t)nst * rtr::kDirK * sizeof(unsigned long long);
+    HIP_TRY(c, hipMalloc((void **)&t.ext0, (size_t)nst * rtr::kS0 * sizeof(uint64_t)));
+    HIP_TRY(c, hipMalloc((void **)&t.dir, dir_bytes));
+    HIP_TRY(c, hipMalloc((void **)&t.fill, (size_t)nst * 4));
+    HIP_TRY(c, hipMalloc((void **)&t.count, (size_t)nst * 4));
+    HIP_TRY(c, hipMalloc((void **)&t.tile_cnt, (size_t)nt * 4));
+    HIP_TRY(c, hipMalloc((void **)&t.items, (size_t)(nt + rtr::kHeavyExtra + 16) * 4));
+    HIP_TRY(c, hipMalloc((void **)&t.hdr, 16 * 4));
+    HIP_TRY(c, hipMalloc((void **)&t.hctr, (size_t)nt * 4));
+    HIP_TRY(c, hipMalloc((void **)&t.ticket, 4));
+    HIP_TRY(c, hipMalloc((void **)&t.pool_next, 8));
+    HIP_TRY(c, hipMemsetAsync(t.dir, 0, dir_bytes, s));  // stamp 0 is never current
+    HIP_TRY(c, hipMemsetAsync(t.fill, 0, (size_t)nst * 4, s));
+    HIP_TRY(c, hipMemsetAsync(t.count, 0, (size_t)nst * 4, s));
+    HIP_TRY(c, hipMemsetAsync(t.tile_cnt, 0, (size_t)nt * 4, s));
+    HIP_TRY(c, hipMemsetAsync(t.hdr, 0, 16 * 4, s));
+    HIP_TRY(c, hipMemsetAsync(t.hctr, 0, (size_t)nt * 4, s));
+    HIP_TRY(c, hipMemsetAsync(t.ticket, 0, 4, s));
+    HIP_TRY(c, hipMemsetAsync(t.pool_next, 0, 8, s));
+    t.seq = 0;
+    f.nst = nst;
+    f.ntiles = nt;
     return RTR_OK;
 }
 
-// Worst-case reservations: a wave region holds every point its wave can see, so list space
-// needs neither atomics nor overflow handling (2 x 12 B x N; sized for a 288 GB part).
+// The dynamic extents of one frame sum to less than twice its entries (every extent doubles its
+// stream, rtr_kernels.h), and a frame has at most n entries: 16 B per point, against the 24 B per
+// point of round 1's wave lists + sorted copy.
 int ensure_lists(rtr_ctx *c) {
-    if (c->F().lists.tiled && c->F().list_n == c->n) return RTR_OK;
-    {
-        auto &f = c->F();
-        dfree(f.lists.tiled); dfree(f.lists.depth); dfree(f.lists.idx); dfree(f.lists.counts); dfree(f.bins.entries);
-        c->list_valid = false;
-    }
-    uint64_t waves = rtr::list_num_waves(c->n, c->opt_grid), cap = rtr::list_region_cap(c->n, c->opt_grid);
-    c->F().lists.region_cap = cap;
-    c->F().list_n = c->n;
-    if (waves == 0) return RTR_OK;
-    size_t bytes = waves * cap * sizeof(uint32_t);
-    HIP_TRY(c, hipMalloc((void **)&c->F().lists.tiled, bytes));
-    HIP_TRY(c, hipMalloc((void **)&c->F().lists.depth, bytes));
-    HIP_TRY(c, hipMalloc((void **)&c->F().lists.idx, bytes));
-    HIP_TRY(c, hipMalloc((void **)&c->F().lists.counts, waves * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void **)&c->F().bins.entries, waves * cap * sizeof(rtr::Entry)));
+    auto &f = c->F();
+    if (f.store.dyn && f.pool_n == c->n) return RTR_OK;
+    dfree(f.store.dyn);
+    c->list_valid = false;
+    f.store.dyn_cap = 2 * c->n + 64;
+    f.pool_n = c->n;
+    HIP_TRY(c, hipMalloc((void **)&f.store.dyn, f.store.dyn_cap * sizeof(uint64_t)));
     return RTR_OK;
 }
 
@@ -253,7 +274,7 @@ rtr::Proj make_proj(const float P[16]) {
     return p;
 }
 
-rtr::Cloud cloud_of(const rtr_ctx *c) { return rtr::Cloud{c->x, c->y, c->z, c->rgba, c->n, c->opt_grid, c->opt_debug}; }
+rtr::Cloud cloud_of(const rtr_ctx *c) { return rtr::Cloud{c->x, c->y, c->z, c->rgba, c->n, c->opt_grid}; }
 
 struct Timed {  // brackets one phase with hipEvents on the stream it is launched on
     rtr_ctx *c; int k; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
@@ -391,16 +412,6 @@ int rtr_create(rtr_ctx **out, int device) {
         delete c;
         return rc;
     }
-    e = hipHostMalloc((void **)&c->stats_host, 2 * sizeof(uint32_t), hipHostMallocMapped);
-    if (e == hipSuccess) {
-        c->stats_host[0] = c->stats_host[1] = 0;
-        void *dptr = nullptr;
-        if (hipHostGetDevicePointer(&dptr, c->stats_host, 0) == hipSuccess)
-            for (auto &f : c->fs) f.bins.stats = static_cast<uint32_t *>(dptr);
-    } else {
-        c->stats_host = nullptr;  // optional: without it the hot-tile fallback is simply off
-        (void)hipGetLastError();
-    }
     *out = c;
     return RTR_OK;
 }
@@ -415,7 +426,6 @@ int rtr_destroy(rtr_ctx *c) {
     free_frame(c);
     free_cloud(c);
     dfree(c->minmax);
-    if (c->stats_host) (void)hipHostFree(c->stats_host);
     if (c->p2p.status_host) (void)hipHostFree(c->p2p.status_host);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -505,10 +515,20 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
     }
     if (!strcmp(key, "point_grid")) {
         NEED(c, value >= 1 && value <= 65535, "point_grid out of range");
-        DevGuard g(c->device);
-        HIP_TRY(c, sync_streams(c));
-        free_lists(c);
         c->opt_grid = value;
+        c->list_valid = false;
+        return RTR_OK;
+    }
+    if (!strcmp(key, "split_threshold")) {  // 0: never split
+        NEED(c, value >= 0, "split_threshold must be >= 0");
+        c->opt_heavy = value;
+        c->list_valid = false;
+        return RTR_OK;
+    }
+    if (!strcmp(key, "split_slice")) {
+        NEED(c, value >= 1, "split_slice must be >= 1");
+        c->opt_slice = value;
+        c->list_valid = false;
         return RTR_OK;
     }
     if (!strcmp(key, "auto_reorder")) {
@@ -517,10 +537,6 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
     }
     if (!strcmp(key, "cull")) {
         c->opt_cull = value != 0;
-        return RTR_OK;
-    }
-    if (!strcmp(key, "debug_skip")) {  // timing experiments only: the frame becomes wrong
-        c->opt_debug = value;
         return RTR_OK;
     }
     if (!strcmp(key, "probe_variant")) {
@@ -671,9 +687,14 @@ int rtr_download_points(rtr_ctx *c, float *xyzw, uint8_t *rgba, uint64_t first, 
     DevGuard g(c->device);
     const uint64_t chunk = 1ull << 24;
     uint64_t m = count < chunk ? count : chunk;
-    float *dx = nullptr; uint8_t *dc = nullptr;
-    HIP_TRY(c, hipMalloc((void **)&dx, m * 16));
-    HIP_TRY(c, hipMalloc((void **)&dc, m * 4));
+    struct Staging {  // freed on every exit path
+        void *p = nullptr;
+        ~Staging() { if (p) (void)hipFree(p); }
+    } stx, stc;
+    HIP_TRY(c, hipMalloc(&stx.p, m * 16));
+    HIP_TRY(c, hipMalloc(&stc.p, m * 4));
+    float *dx = static_cast<float *>(stx.p);
+    uint8_t *dc = static_cast<uint8_t *>(stc.p);
     for (uint64_t off = 0; off < count; off += chunk) {
         uint64_t cnt = (count - off) < chunk ? (count - off) : chunk;
         uint64_t s0 = first + off;
@@ -682,7 +703,6 @@ int rtr_download_points(rtr_ctx *c, float *xyzw, uint8_t *rgba, uint64_t first, 
         HIP_TRY(c, hipMemcpyAsync(rgba + off * 4, dc, cnt * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, sync_streams(c));
     }
-    dfree(dx); dfree(dc);
     return launch_check(c, "soa_to_aos");
 }
 
@@ -748,10 +768,12 @@ static bool use_tiles(const rtr_ctx *c) {
     return c->opt_mode == 1 && !c->force_atomic && rtr::tile_count(c->W, c->H) <= 4096;
 }
 
-// T1..T3 of the tile-binned form: stream + candidate lists + tile histogram, scan, scatter
+// T1 of the tile-binned form: stream the cloud, append the in-frustum points to the tile store; its
+// last workgroup writes the tile kernel's work list (and resets the tiles that will be split when
+// the tile launches are the frame buffers' only writers: `clear_split`).
 // With `overlapped` T1 goes to the front stream and fills the set the tail is NOT reading, so it
-// runs beside T2..F5 of the previous frame (which are latency-bound and leave HBM idle).
-static int bin_points(rtr_ctx *c, const float P[16], bool overlapped = false) {
+// runs beside T4 / the prefilter of the previous frame.
+static int bin_points(rtr_ctx *c, const float P[16], bool overlapped, bool clear_split) {
     c->list_valid = false;
     c->p2p.occ_current = false;
     c->p2p.occ_from_scan = false;
@@ -763,27 +785,23 @@ static int bin_points(rtr_ctx *c, const float P[16], bool overlapped = false) {
     }
     if (int rc = ensure_lists(c)) return rc;
     if (int rc = ensure_tiles(c, s1)) return rc;
-    {
-        size_t need = (size_t)(rtr::list_num_waves(c->n, c->opt_grid) / 4 + 1) * (size_t)c->F().tiles_n;
-        if (!c->F().bins.blk_hist || c->F().blk_hist_n != need) {
-            dfree(c->F().bins.blk_hist);
-            HIP_TRY(c, hipMalloc((void **)&c->F().bins.blk_hist, need * sizeof(uint32_t)));
-            c->F().blk_hist_n = need;
-        }
+    auto &t = c->F().store;
+    t.seq = (t.seq + 1u) & 0xFFFFFFu;
+    if (t.seq == 0u) {  // the 24-bit stamp wrapped: forget every directory entry once
+        HIP_TRY(c, hipMemsetAsync(t.dir, 0, (size_t)c->F().nst * rtr::kDirK * sizeof(unsigned long long), s1));
+        t.seq = 1u;
     }
+    t.heavy = c->opt_heavy > 0 ? (uint32_t)c->opt_heavy : 0xFFFFFFFFu;
+    t.slice = (uint32_t)c->opt_slice;
     {
-        Timed t(c, RTR_K_MIN_DEPTH, s1);
-        rtr::launch_project_bin(s1, cloud_of(c), make_proj(P), c->W, c->H, c->F().lists, c->F().bins.tile_hist,
-                                c->F().bins.blk_hist, c->opt_cull ? c->bounds : nullptr);
+        Timed tm(c, RTR_K_MIN_DEPTH, s1);
+        rtr::launch_project_bin(s1, cloud_of(c), make_proj(P), c->W, c->H, t, c->opt_cull ? c->bounds : nullptr,
+                                clear_split ? 1 : 0, c->depth, c->acc, c->p2p.open ? c->p2p.occ : nullptr);
+        c->p2p.occ_from_scan = c->p2p.open;
     }
     if (overlapped) {
         HIP_TRY(c, hipEventRecord(c->F().binned, c->front));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->F().binned, 0));
-    }
-    {
-        Timed t(c, RTR_K_BIN);
-        rtr::launch_bin_sort(c->stream, cloud_of(c), c->W, c->H, c->F().lists, c->F().bins, c->p2p.open ? c->p2p.occ : nullptr);
-        c->p2p.occ_from_scan = c->p2p.open;
     }
     memcpy(c->list_P, P, sizeof c->list_P);
     c->list_valid = true;
@@ -797,9 +815,9 @@ int rtr_min_depth_pass(rtr_ctx *c, const float P[16]) {
     DevGuard g(c->device);
     c->list_valid = false;
     if (use_tiles(c)) {
-        if (int rc = bin_points(c, P)) return rc;
+        if (int rc = bin_points(c, P, false, c->p2p.whole_frame)) return rc;
         Timed t(c, RTR_K_TILE);
-        rtr::launch_tile(c->stream, 1, cloud_of(c), c->W, c->H, c->F().bins, c->prm.depth_window, c->depth, c->acc, c->img,
+        rtr::launch_tile(c->stream, 1, c->W, c->H, c->F().store, c->prm.depth_window, c->depth, c->acc, c->img,
                          c->p2p.whole_frame ? 2 : 0, nullptr);
         mark_consumed(c);
     } else {
@@ -837,7 +855,7 @@ int rtr_accumulate_pass(rtr_ctx *c, const float P[16]) {
         }
         c->p2p.depth_sliced = false;
         Timed t(c, RTR_K_TILE);
-        rtr::launch_tile(c->stream, 2, cloud_of(c), c->W, c->H, c->F().bins, c->prm.depth_window, c->depth, c->acc, c->img,
+        rtr::launch_tile(c->stream, 2, c->W, c->H, c->F().store, c->prm.depth_window, c->depth, c->acc, c->img,
                          c->p2p.whole_frame ? 2 : 0, pyr.enable ? &pyr : nullptr, dsl.chunk ? &dsl : nullptr);
         mark_consumed(c);
     } else {
@@ -895,21 +913,9 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
         if (int rc = ensure_pyramid(c)) return rc;
     }
     int rc;
-    // Hot-tile fallback: T4 gives a whole tile to one workgroup, so a view that packs most of
-    // the cloud into a few tiles (a distant overview) would serialise there.  The scan kernel
-    // reports the heaviest tile of each frame through mapped host memory; it is read here
-    // WITHOUT synchronisation (a frame or two stale -- it only steers speed, both forms produce
-    // the same frame).  While the heaviest tile exceeds 2^18 entries the atomic form is used,
-    // and the binned form is probed again every 16th frame.
-    bool tiles = use_tiles(c);
-    if (tiles && c->stats_host && c->stats_host[1] > (1u << 18)) {
-        if (++c->atomic_frames % 16 != 0) tiles = false;
-    } else {
-        c->atomic_frames = 0;
-    }
-    if (tiles) {  // one launch does clear + min + accumulate + resolve per tile
+    if (use_tiles(c)) {  // one launch does clear + min + accumulate + resolve per tile
         DevGuard g(c->device);
-        if ((rc = bin_points(c, P, c->opt_overlap && c->front))) return rc;
+        if ((rc = bin_points(c, P, c->opt_overlap && c->front, true))) return rc;
         // with the default four levels the tile kernel also emits the prefilter's pyramid and
         // min / max partials (F1) while the finished depth tile is still in LDS
         rtr::TilePyr pyr{};
@@ -922,8 +928,13 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
         }
         {
             Timed t(c, RTR_K_TILE);
-            rtr::launch_tile(c->stream, 0, cloud_of(c), c->W, c->H, c->F().bins, c->prm.depth_window, c->depth, c->acc,
-                             c->img, c->opt_keep_accum, pyr.enable ? &pyr : nullptr);
+            rtr::launch_tile(c->stream, 0, c->W, c->H, c->F().store, c->prm.depth_window, c->depth, c->acc, c->img,
+                             c->opt_keep_accum, pyr.enable ? &pyr : nullptr);
+            // tiles heavier than option "split_threshold" were split over several workgroups; their slices
+            // have met in the depth buffer, this launch accumulates them against that minimum and the last
+            // slice of each tile resolves it (no work item on ordinary frames: 512 workgroups leave at once)
+            rtr::launch_tile(c->stream, 3, c->W, c->H, c->F().store, c->prm.depth_window, c->depth, c->acc, c->img,
+                             c->opt_keep_accum, pyr.enable ? &pyr : nullptr);
         }
         mark_consumed(c);
         if ((rc = launch_check(c, "tile frame"))) return rc;
@@ -1078,7 +1089,7 @@ int rtr_p2p_min_depth(rtr_ctx *c) {
     // which screen tiles this rank's frame touches at all (only known when it came from the bins)
     const bool binned = use_tiles(c) && c->list_valid;
     if (!(binned && q.occ_from_scan))  // otherwise the scan kernel of the tile sort has already written it
-        rtr::launch_p2p_occupancy(c->stream, binned ? c->F().bins.tile_start : nullptr, c->W, c->H, q.occ);
+        rtr::launch_p2p_occupancy(c->stream, binned ? c->F().store.tile_cnt : nullptr, c->W, c->H, q.occ);
     q.occ_current = binned;
     q.acc_from_bins = false;
     p2p_barrier(c);  // every rank's local depth (and occupancy) is complete
@@ -1178,6 +1189,16 @@ int rtr_download_buffer(rtr_ctx *c, int which, void *host, size_t bytes) {
 }
 
 // ---- measurement -------------------------------------------------------------------
+
+int rtr_frame_stats(rtr_ctx *c, uint32_t out[8]) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, out != nullptr, "out is NULL");
+    NEED(c, c->F().store.hdr != nullptr, "no binned frame yet");
+    DevGuard g(c->device);
+    HIP_TRY(c, hipMemcpyAsync(out, c->F().store.hdr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, sync_streams(c));
+    return RTR_OK;
+}
 
 int rtr_timing_enable(rtr_ctx *c, int on) {
     if (!c) return RTR_ERR_INVALID;

@@ -17,9 +17,7 @@ struct Cloud {
     const float *x, *y, *z;  // SoA, padded to a multiple of 4 points with NaN
     const uint32_t *rgba;    // packed c0 | c1<<8 | c2<<16 | 255<<24
     uint64_t n;              // real point count
-    int grid;                // workgroups of the grid-stride point kernels (lists are sized for it)
-    int debug;               // timing experiments only (frames become wrong): bit1 T3 move, bit2/3/4 T4 min/acc/
-                             // write-out, bit5 T4 no colour gather, bit6 T1 no list stores, bit7 T1 no LDS histogram
+    int grid;                // workgroups of the grid-stride point kernels
 };
 
 struct FilterLevels {
@@ -28,12 +26,6 @@ struct FilterLevels {
     int levels;
 };
 
-// wave-private candidate lists (SoA) written by T1 and the tile-sorted copy made by T3
-struct Lists {
-    uint32_t *tiled, *depth, *idx;  // [num_waves * region_cap] each
-    uint32_t *counts;               // [num_waves]
-    uint64_t region_cap;
-};
 // peer-to-peer exchange (see the comment on k_p2p_sync): p[r] = rank r's buffer as mapped into this process
 constexpr int kMaxPeers = 16;
 struct PeerSet {
@@ -52,16 +44,33 @@ struct TilePyr {  // F1 folded into T4 (whole-frame calls with the default 4 lev
     uint32_t *part_min, *part_max;
     int enable;
 };
-struct Entry {  // 12 bytes, moved with one dwordx3 store
-    uint32_t tiled, depth, idx;
+// Tile store of the binned form.  Every 32x16 screen "storage tile" owns a stream of 8-byte
+// entries (depth bits << 33 | in-tile pixel << 24 | colour), appended by T1 straight in tile order:
+// the stream's first kS0 entries live in a static extent, later ones in extents of doubling size
+// handed out on demand from `dyn` (extent k >= 1 holds stream positions [kS0 << (k-1), kS0 << k)).
+constexpr int kS0Shift = 12;             // static extent: 4096 entries = 32 KB per storage tile
+constexpr uint32_t kS0 = 1u << kS0Shift;
+constexpr int kDirK = 21;                // extents 1..20 reach 2^32 entries per storage tile
+constexpr int kHeavyExtra = 512;         // extra tile-kernel workgroups available for split tiles
+struct TileStore {
+    uint64_t *ext0;                 // [nst * kS0]
+    uint64_t *dyn;                  // [dyn_cap] pool of the dynamic extents
+    unsigned long long *pool_next;  // entries of `dyn` handed out in this frame
+    unsigned long long *dir;        // [nst * kDirK] extent base << 24 | frame stamp (valid iff stamp == seq)
+    uint32_t *fill;                 // [nst] stream length while T1 runs; zero between frames
+    uint32_t *count;                // [nst] stream lengths of the binned frame (T1's last workgroup)
+    uint32_t *tile_cnt;             // [ntiles] entries per processing tile (32x32 or 64x32 pixels)
+    uint32_t *items;                // [ntiles + kHeavyExtra] work list of the tile kernel:
+                                    //   tile | sub << 12 | (nsub - 1) << 22; split tiles first
+    uint32_t *hdr;                  // [16] see kHdr*
+    uint32_t *hctr;                 // [ntiles] arrival counters of split tiles
+    uint32_t *ticket;               // T1 workgroups that have finished
+    uint64_t dyn_cap;
+    uint32_t seq;                   // 24-bit frame stamp, never 0
+    uint32_t heavy, slice;          // split tiles with more entries than `heavy` into slices of >= `slice`
 };
-struct Bins {
-    Entry *entries;                             // entries counting-sorted by tile
-    uint32_t *tile_hist, *tile_start, *cursor;  // [ntiles], [ntiles + 1], [ntiles]
-    uint32_t *order;                            // [ntiles]: tile launch order of T4, heavy tiles first
-    uint32_t *stats;                            // [2] in mapped HOST memory: entries of the frame, of its heaviest tile
-    uint32_t *blk_hist;                         // [point-grid workgroups][ntiles]: T1's per-workgroup counts
-};
+enum { kHdrItems = 0, kHdrSplitItems = 1, kHdrEntries = 2, kHdrHeaviest = 3, kHdrSlice = 4, kHdrError = 5,
+       kHdrSplitTiles = 6 };
 
 void launch_clear(hipStream_t s, uint32_t *depth, uint32_t *acc, size_t npix);
 // mode 0: the reference's structure (two full streams, global atomics)
@@ -71,18 +80,22 @@ void launch_accumulate(hipStream_t s, const Cloud &c, const Proj &P, int W, int 
 // mode 1 (default): tile-binned pipeline -- T1 stream + lists + histogram, T2 scan + T3 scatter,
 // T4 per-tile LDS z-buffer (tile mode 0 whole frame, 1 min only, 2 accumulate only)
 constexpr int kDefaultPointGrid = 1024;
-uint64_t list_region_cap(uint64_t n, int grid);  // entries per wave region
-uint64_t list_num_waves(uint64_t n, int grid);   // number of wave regions
-int tile_count(int W, int H);
+int tile_count(int W, int H);          // processing tiles (32x32, or 64x32 above 4096 of them)
+int storage_tile_count(int W, int H);  // 32x16 storage tiles
+// T1: stream the cloud once, append every in-frustum point to its storage tile's stream; the last
+// workgroup to finish turns the stream lengths into the tile kernel's work list (and, with
+// `clear_split`, resets depth / accumulators of the tiles that will be split; `occ`: 128-word tile
+// occupancy bitmap for the peer-to-peer exchange, may be NULL).
 // bounds != NULL enables per-chunk frustum culling (see k_project_bin)
-void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const Lists &L,
-                        uint32_t *tile_hist, uint32_t *blk_hist, const float *bounds);
+void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const TileStore &S,
+                        const float *bounds, int clear_split, uint32_t *depth, uint32_t *acc, uint32_t *occ);
 void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds);  // 6 floats per 256 points
 int reorder_morton(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, uint64_t n);  // rtr_reorder.hip
-// occ (optional): 128 words, one bit per tile that has entries (peer-to-peer exchange)
-void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const Lists &L, const Bins &B, uint32_t *occ = nullptr);
+// T4: per-tile LDS z-buffer over the tile store.  mode 0 = whole frame (min + accumulate + resolve
+// of every unsplit tile, min phase of split tiles), 3 = second phase of the split tiles of a whole
+// frame, 1 = min only, 2 = accumulate only.
 // depth_slices (mode 2 only): read the global depth from the ranks' reduced slices and store it to `depth`
-void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const Bins &B, float window, uint32_t *depth,
+void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, float window, uint32_t *depth,
                  uint32_t *acc, uint8_t *img, int write_acc, const TilePyr *pyr, const Sliced *depth_slices = nullptr);
 void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *sink, int variant);
 void launch_resolve(hipStream_t s, const uint32_t *acc, uint8_t *img, size_t npix);
@@ -93,7 +106,7 @@ void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, u
 void launch_p2p_sync(hipStream_t s, uint32_t *my_flags, const PeerSet &peer_flags, int rank, int world, uint32_t seq,
                      uint32_t *status, unsigned long long timeout_ticks);
 constexpr int kP2POccBytes = 512;  // occupancy bitmap: one bit per screen tile (<= 4096)
-void launch_p2p_occupancy(hipStream_t s, const uint32_t *tile_start, int W, int H, uint32_t *occ);
+void launch_p2p_occupancy(hipStream_t s, const uint32_t *tile_cnt, int W, int H, uint32_t *occ);
 void launch_p2p_depth_reduce(hipStream_t s, const PeerSet &depth, const PeerSet &occ, uint32_t *red, size_t first,
                              size_t count, int world, int W, int H);
 void launch_p2p_gather(hipStream_t s, const PeerSet &src, void *dst, size_t chunk_bytes, size_t nbytes,

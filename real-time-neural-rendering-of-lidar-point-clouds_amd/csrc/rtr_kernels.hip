@@ -93,28 +93,6 @@ __device__ __forceinline__ uint32_t ld_fresh(const uint32_t *p) {  // sc1: bypas
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// LDS histogram update with wave-level aggregation.  Same-address LDS atomics serialise
-// (measured: 6.7 M single-lane ds_add on mostly equal keys cost 20 us chip-wide), and in a
-// spatially coherent cloud nearly every lane of a wave carries the same tile.  The lanes
-// that share the first valid lane's key are handled by ONE atomic of their popcount; the
-// remaining lanes (tile borders, incoherent clouds) fall back to one atomic each.
-// Returns the value the lane's own "atomicAdd(&hist[key], 1)" would have returned.
-__device__ __forceinline__ uint32_t lds_hist_add(uint32_t *hist, uint32_t key, bool valid) {
-    const unsigned long long vm = __ballot(valid);
-    if (vm == 0ull) return 0u;
-    const int lane = threadIdx.x & 63;
-    const int first = __ffsll((long long)vm) - 1;
-    const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
-    const bool grp = valid && key == lead;
-    const unsigned long long gm = __ballot(grp);
-    uint32_t base = 0u;
-    if (lane == first) base = atomicAdd(&hist[lead], (uint32_t)__popcll(gm));
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-    uint32_t res = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(gm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)gm, 0u));
-    if (valid && !grp) res = atomicAdd(&hist[key], 1u);
-    return res;
-}
-
 static int point_grid(uint64_t n4, int grid) {
     uint64_t blocks = (n4 + kBlock - 1) / kBlock;
     uint64_t cap = grid < 1 ? 1 : (uint64_t)grid;
@@ -348,26 +326,33 @@ void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, in
 // Scattered device-scope atomics run at a few 10^10 per second on MI355X (they execute
 // at the memory side), which is what bounds the atomic form above once the stream itself
 // runs at ~6 TB/s.  The binned form has NO global atomics on the frame buffers:
-//   T1 k_project_bin : stream the cloud once (12 B/pt), append every in-frustum point as
-//                      (tile-major pixel index, depth bits, point index) to SoA lists
-//                      private to the wave, count points per 32-row screen tile in LDS;
-//   T2 k_tile_scan   : exclusive scan of the tile histogram (one workgroup);
-//   T3 k_scatter     : counting-sort the entries by tile (LDS ranks, one contiguous
-//                      atomic claim per workgroup and tile);
-//   T4 k_tile<>      : one workgroup per tile keeps the tile's depth and accumulators in
-//                      LDS: ds_min (render.cu:81), barrier, window test + ds_add
+//   T1 k_project_bin : stream the cloud once (12 B/pt); every in-frustum point becomes ONE
+//                      8-byte entry (depth bits, in-tile pixel, colour) appended straight to the
+//                      stream of its 32x16 "storage tile" -- one returning atomic per wave and
+//                      tile claims the positions, so the entries are written once, already in
+//                      tile order (round 1 wrote wave lists, scanned and counting-sorted them:
+//                      three launches and 0.39 GB for 0.08 GB of entries).  The last workgroup
+//                      to finish turns the stream lengths into the tile kernel's work list;
+//   T4 k_tile<>      : one workgroup per 32x32 (64x32) tile keeps the tile's depth and
+//                      accumulators in LDS: ds_min (render.cu:81), barrier, window test + ds_add
 //                      (render.cu:106,125-128), barrier, resolve (render.cu:147-162) and
 //                      writes every pixel of the tile -- clear, both reference passes and
-//                      the resolve of one tile in one launch.
+//                      the resolve of one tile in one launch.  A tile with more than
+//                      TileStore::heavy entries is split over several workgroups (slices of its
+//                      streams, private LDS z-buffers): their minima meet in the depth buffer
+//                      (atomicMin), a second launch accumulates the slices against that global
+//                      minimum into the accumulators, and its last workgroup per tile resolves.
 // Results are identical to the atomic form because min and integer sums commute.
 constexpr int kTileH = 32;
 constexpr int kTileThreads = 512;
-constexpr int kTileBatch = 8;   // entries in flight per thread in k_tile
-constexpr int kScatterWPR = 2;  // k_scatter waves per list region
+constexpr int kTileBatch = 8;    // entries in flight per thread in k_tile
+constexpr int kMaxGroups = 3;    // tile groups of a quad that get a wave-level claim; the rest claim per lane
+constexpr int kMaxSegs = 4 * kDirK;
 
 struct TileGeom {
-    int tw_shift;  // log2(tile width): 5 (32x32) or 6 (64x32)
+    int tw_shift;  // log2(processing tile width): 5 (32x32) or 6 (64x32)
     int tiles_x, tiles_y, ntiles;
+    int stx, sty, nst;  // 32x16 storage tiles
 };
 
 __host__ __device__ inline TileGeom tile_geom(int W, int H) {
@@ -375,34 +360,258 @@ __host__ __device__ inline TileGeom tile_geom(int W, int H) {
     g.tw_shift = 5;
     g.tiles_x = (W + 31) >> 5;
     g.tiles_y = (H + kTileH - 1) / kTileH;
-    if (g.tiles_x * g.tiles_y > 4096) {  // keep the LDS histogram <= 16 KB (4K frames); the host falls
-                                         // back to the atomic form when even 64-wide tiles exceed 4096
+    if (g.tiles_x * g.tiles_y > 4096) {  // work-list items carry 12 tile bits and the peer-to-peer occupancy
+                                         // bitmap 4096 bits (4K frames); the host falls back to the atomic
+                                         // form when even 64-wide tiles exceed 4096
         g.tw_shift = 6;
         g.tiles_x = (W + 63) >> 6;
     }
     g.ntiles = g.tiles_x * g.tiles_y;
+    g.stx = (W + 31) >> 5;
+    g.sty = (H + 15) >> 4;
+    g.nst = g.stx * g.sty;
     return g;
 }
 
 int tile_count(int W, int H) { return tile_geom(W, H).ntiles; }
+int storage_tile_count(int W, int H) { return tile_geom(W, H).nst; }
 
-uint64_t list_region_cap(uint64_t n, int grid) {  // entries one wave can produce: its iterations x 64 lanes x 4 points
-    uint64_t n4 = (n + 3) / 4;
-    if (n4 == 0) return 0;
-    uint64_t threads = (uint64_t)point_grid(n4, grid) * kBlock;
-    return ((n4 + threads - 1) / threads) * 256;
+// entry = depth bits (31: positive floats) << 33 | pixel inside the 32x16 storage tile (9) << 24 | colour (24)
+__device__ __forceinline__ unsigned long long make_entry(uint32_t depth_bits, uint32_t pix9, uint32_t colour) {
+    return ((unsigned long long)depth_bits << 33) | ((unsigned long long)pix9 << 24) | (unsigned long long)(colour & 0xFFFFFFu);
 }
 
-uint64_t list_num_waves(uint64_t n, int grid) {
-    uint64_t n4 = (n + 3) / 4;
-    return n4 ? (uint64_t)point_grid(n4, grid) * (kBlock / 64) : 0;
+__device__ __forceinline__ void store_error(const TileStore &S, uint32_t code) { atomicOr(S.hdr + kHdrError, code); }
+
+// Stream position v >= kS0 of storage tile st lies in extent k, which holds [kS0 << (k-1), kS0 << k).
+// The lane that claimed an extent's FIRST position allocates it (one returning add on the pool
+// cursor) and publishes base | stamp as one 8-byte word; every other lane polls that word.
+// A wave discharges ALL its allocation duties (extent_alloc over its four points) before any of
+// its lanes polls (extent_slot): an allocator then never waits for anything, so the polls of all
+// waves terminate -- polling for a peer's extent on one point while still owing an allocation on
+// a later one is a circular wait between two waves.  The polls are bounded all the same.
+__device__ __forceinline__ unsigned long long extent_alloc(const TileStore &S, uint32_t st, uint32_t v) {
+    const int k = 32 - __clz((int)(v >> kS0Shift));  // 1..20
+    const uint32_t start = kS0 << (k - 1);           // first position = size of extent k
+    if (v != start) return 0ull;
+    const unsigned long long base = atomicAdd(S.pool_next, (unsigned long long)start);
+    const unsigned long long e = (base << 24) | (unsigned long long)S.seq;
+    __hip_atomic_store(S.dir + (size_t)st * kDirK + k, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return e;
+}
+__device__ __forceinline__ uint64_t *extent_slot(const TileStore &S, uint32_t st, uint32_t v, unsigned long long own) {
+    const int k = 32 - __clz((int)(v >> kS0Shift));
+    const uint32_t start = kS0 << (k - 1);
+    unsigned long long e = own;
+    if (e == 0ull) {
+        const unsigned long long *d = S.dir + (size_t)st * kDirK + k;
+        int polls = 0;
+        for (;;) {
+            e = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(e & 0xFFFFFFull) == S.seq) break;
+            if (++polls > (1 << 22)) {
+                store_error(S, 1u);
+                return nullptr;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    const unsigned long long base = e >> 24;
+    if (base + start > S.dyn_cap) {  // cannot happen: the extents of a frame sum to < 2 x its entries
+        store_error(S, 2u);
+        return nullptr;
+    }
+    return S.dyn + base + (v - start);
+}
+
+// inclusive scan over a 256-thread workgroup; returns the inclusive prefix, `total` = sum of all
+__device__ __forceinline__ uint32_t block_scan256(uint32_t v, uint32_t *s_w /*[4]*/, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    __syncthreads();  // s_w may still be read from the previous scan
+    if (lane == 63) s_w[wv] = v;
+    __syncthreads();
+    uint32_t base = 0;
+    total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t w = s_w[k];
+        base += k < wv ? w : 0u;
+        total += w;
+    }
+    return v + base;
+}
+__device__ __forceinline__ uint32_t block_max256(uint32_t v, uint32_t *s_w) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t m = s_w[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) m = s_w[k] > m ? s_w[k] : m;
+    return m;
+}
+
+// storage tile of stream s (0 .. 2 or 4) of processing tile (tx, ty); -1 when outside the frame
+__device__ __forceinline__ int stream_tile(const TileGeom &g, int tx, int ty, int s) {
+    const int per_row = 1 << (g.tw_shift - 5);
+    const int sx = tx * per_row + (s & (per_row - 1)), sy = ty * 2 + (s >> (g.tw_shift - 5));
+    return (sx < g.stx && sy < g.sty) ? sy * g.stx + sx : -1;
+}
+
+// The bookkeeping of a binned frame, run by the LAST workgroup of T1 (every stream length is final:
+// each wave waited for its own returning adds before its workgroup took a ticket):
+//   count[] <- fill[], fill[] <- 0, entries per processing tile, the tile kernel's work list (split
+//   tiles first, then tiles with more than twice the mean entry count, then the rest), frame
+//   statistics, the occupancy bitmap of the peer-to-peer exchange, and the pool / ticket reset.
+__device__ void bin_epilogue(const TileStore &S, const TileGeom &g, int W, int H, int clear_split,
+                             uint32_t *__restrict__ depth, uint32_t *__restrict__ acc, uint32_t *__restrict__ occ) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_occ[128];
+    __shared__ uint32_t s_split[64];  // tiles to reset (more are reset by a second sweep)
+    __shared__ uint32_t s_nsplit;
+    const int t = threadIdx.x;
+    if (t < 128) s_occ[t] = 0;
+    if (t == 0) s_nsplit = 0;
+    constexpr int PER = 16;  // 256 threads x 16 = 4096 tiles
+    uint32_t sum = 0, mx = 0, heavy_sum = 0, heavy_n = 0;
+    const int per_tile = 2 << (g.tw_shift - 5);
+#pragma unroll 1
+    for (int k = 0; k < PER; ++k) {
+        const int tile = t * PER + k;
+        uint32_t c = 0;
+        if (tile < g.ntiles) {
+            const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+            for (int s = 0; s < per_tile; ++s) {
+                const int st = stream_tile(g, tx, ty, s);
+                if (st < 0) continue;
+                const uint32_t f = __hip_atomic_load(S.fill + st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                S.count[st] = f;
+                S.fill[st] = 0;
+                c += f;
+            }
+            S.tile_cnt[tile] = c;  // re-read below by this same thread
+        }
+        sum += c;
+        mx = c > mx ? c : mx;
+        if (c > S.heavy) {
+            heavy_sum += c;  // (a frame has < 2^32 entries)
+            heavy_n += 1;
+        }
+    }
+    uint32_t total = 0, heavy_total = 0, n_heavy = 0;
+    block_scan256(sum, s_w, total);
+    block_scan256(heavy_sum, s_w, heavy_total);
+    block_scan256(heavy_n, s_w, n_heavy);
+    mx = block_max256(mx, s_w);
+    // slice size: sum of ceil(cnt / slice) over the split tiles <= heavy_total / slice + n_heavy, and the
+    // list has room for ntiles + kHeavyExtra items, of which the unsplit tiles take ntiles - n_heavy
+    uint32_t slice = S.slice < 1u ? 1u : S.slice;
+    {
+        const uint32_t need = (uint32_t)(((unsigned long long)heavy_total + kHeavyExtra - 1) / kHeavyExtra);
+        slice = need > slice ? need : slice;
+        const uint32_t need2 = (mx + 1023u) / 1024u;  // nsub - 1 has 10 bits
+        slice = need2 > slice ? need2 : slice;
+    }
+    // split tiles: items [0, n_split_items), one per slice
+    uint32_t my_sub = 0;
+#pragma unroll 1
+    for (int k = 0; k < PER; ++k) {
+        const int tile = t * PER + k;
+        const uint32_t c = tile < g.ntiles ? S.tile_cnt[tile] : 0u;
+        if (c > S.heavy) my_sub += (c + slice - 1) / slice;
+    }
+    uint32_t n_split_items = 0;
+    uint32_t pos = block_scan256(my_sub, s_w, n_split_items) - my_sub;
+#pragma unroll 1
+    for (int k = 0; k < PER; ++k) {
+        const int tile = t * PER + k;
+        const uint32_t c = tile < g.ntiles ? S.tile_cnt[tile] : 0u;
+        if (c > S.heavy) {
+            const uint32_t nsub = (c + slice - 1) / slice;
+            for (uint32_t j = 0; j < nsub; ++j) S.items[pos + j] = (uint32_t)tile | (j << 12) | ((nsub - 1u) << 22);
+            pos += nsub;
+            S.hctr[tile] = 0;
+            const uint32_t q = atomicAdd(&s_nsplit, 1u);
+            if (q < 64u) s_split[q] = (uint32_t)tile;
+        }
+    }
+    // unsplit tiles: those with more than twice the mean entry count first, so the few heavy tiles
+    // that bound T4 start at once instead of trailing the launch
+    const uint32_t thr = 2u * (total / (uint32_t)g.ntiles) + 1u;
+    uint32_t big = 0, light = 0;
+#pragma unroll 1
+    for (int k = 0; k < PER; ++k) {
+        const int tile = t * PER + k;
+        const uint32_t c = tile < g.ntiles ? S.tile_cnt[tile] : 0u;
+        if (tile < g.ntiles && c <= S.heavy) {
+            light += 1;
+            big += c > thr ? 1u : 0u;
+        }
+    }
+    uint32_t n_big = 0, n_light = 0;
+    uint32_t big_before = block_scan256(big, s_w, n_big) - big;
+    uint32_t light_before = block_scan256(light, s_w, n_light) - light;
+#pragma unroll 1
+    for (int k = 0; k < PER; ++k) {
+        const int tile = t * PER + k;
+        const uint32_t c = tile < g.ntiles ? S.tile_cnt[tile] : 0u;
+        if (tile < g.ntiles && c <= S.heavy) {
+            const bool b = c > thr;
+            const uint32_t p = n_split_items + (b ? big_before : n_big + (light_before - big_before));
+            S.items[p] = (uint32_t)tile;
+            big_before += b ? 1u : 0u;
+            light_before += 1u;
+        }
+        if (c) atomicOr(&s_occ[tile >> 5], 1u << (tile & 31));
+    }
+    __syncthreads();
+    if (occ && t < 128) occ[t] = s_occ[t];
+    if (t == 0) {
+        S.hdr[kHdrItems] = n_split_items + n_light;
+        S.hdr[kHdrSplitItems] = n_split_items;
+        S.hdr[kHdrEntries] = total;
+        S.hdr[kHdrHeaviest] = mx;
+        S.hdr[kHdrSlice] = slice;
+        S.hdr[kHdrSplitTiles] = n_heavy;
+        *S.pool_next = 0ull;
+        *S.ticket = 0u;
+    }
+    // Whole frames (and sharded frames whose tile launches are the only writers) never clear the frame
+    // buffers: an unsplit tile is written by its one workgroup.  The slices of a split tile meet in
+    // memory (atomicMin / atomicAdd), which therefore has to start from the sentinel / zero.
+    if (clear_split && n_heavy) {
+        const int tw = 1 << g.tw_shift, tpix = 32 << g.tw_shift;
+        const uint32_t listed = s_nsplit < 64u ? s_nsplit : 64u;
+        auto reset_tile = [&](int tile) {
+            const int tx0 = (tile % g.tiles_x) << g.tw_shift, ty0 = (tile / g.tiles_x) * kTileH;
+            for (int p = t; p < tpix; p += kBlock) {
+                const int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
+                if (x < W && y < H) {
+                    const size_t gp = (size_t)y * W + x;
+                    depth[gp] = RTR_EMPTY;
+                    reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+        };
+        if (n_heavy <= 64u) {
+            for (uint32_t q = 0; q < listed; ++q) reset_tile((int)s_split[q]);
+        } else {
+            for (int tile = 0; tile < g.ntiles; ++tile)
+                if (S.tile_cnt[tile] > S.heavy) reset_tile(tile);  // written by this workgroup above (barrier passed)
+        }
+    }
 }
 
 // T1 ------------------------------------------------------------------------------
-// Wave-private list regions need no atomics and no overflow handling: the write position is
-// a wave-uniform counter advanced by ballot popcounts, a region holds every point its wave
-// can ever see.
-//
 // VALU matters here (a loads-only probe streams at 6.9 TB/s, with the projection arithmetic
 // at 6.0), so the quad is culled in three wave-uniform steps before the expensive part:
 //   1. r.z of the four points (render.cu:37,63); skip the quad if no lane has r.z > 0;
@@ -413,6 +622,12 @@ uint64_t list_num_waves(uint64_t n, int grid) {
 //      underflow enters the argument.  Skip the quad if no lane may be inside;
 //   3. the exact contract arithmetic (reciprocal, rintf, range test) for what is left.
 // Spatially coherent clouds (LiDAR block order) take the early exits for ~90 % of the waves.
+//
+// Append: the in-frustum points of a quad (up to 256 per wave) are grouped by storage tile with
+// ballots -- consecutive points are spatial neighbours, so one to three tiles cover them -- and
+// each group claims its run of stream positions with ONE returning atomic add issued by one lane;
+// all claims of a quad, and the 16-byte colour load of the lanes that need it, are in flight
+// together and waited for once.  Points of further tiles (incoherent clouds) claim per lane.
 //
 // CULL (option "cull", off by default, reported separately from the roofline figure): each
 // wave first tests the bounding box of its 256-point chunk (k_chunk_bounds, 24 B per chunk)
@@ -425,22 +640,17 @@ uint64_t list_num_waves(uint64_t n, int grid) {
 // Only spatially coherent point orders have tight chunk boxes (rtr_reorder_points).
 template <bool CULL>
 __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
-                                                        const float4 *__restrict__ z4, uint64_t n4, Proj P, int W,
-                                                        int H, TileGeom g, Lists L, uint32_t *__restrict__ tile_hist,
-                                                        uint32_t *__restrict__ blk_hist,
-                                                        const float *__restrict__ bounds, int dbg) {
-    extern __shared__ uint32_t s_hist[];
-    for (int t = threadIdx.x; t < g.ntiles; t += kBlock) s_hist[t] = 0;
-    __syncthreads();
+                                                        const float4 *__restrict__ z4,
+                                                        const uint4 *__restrict__ rgba4, uint64_t n4, Proj P, int W,
+                                                        int H, TileGeom g, TileStore S,
+                                                        const float *__restrict__ bounds, int clear_split,
+                                                        uint32_t *__restrict__ depth, uint32_t *__restrict__ acc,
+                                                        uint32_t *__restrict__ occ) {
     const float fW = (float)W, fH = (float)H;
     const float hiW = f_add(fW, 0.25f), hiH = f_add(fH, 0.25f);
     const uint64_t gtid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const int lane = threadIdx.x & 63;
-    const int tshift = g.tw_shift + 5, twm = (1 << g.tw_shift) - 1;
-    const uint64_t base = (gtid >> 6) * L.region_cap;
-    uint32_t *__restrict__ my_t = L.tiled + base, *__restrict__ my_d = L.depth + base, *__restrict__ my_i = L.idx + base;
-    uint32_t fill = 0;
 
     // one quad (four points per lane) of the wave; every exit is wave-uniform
     auto do_quad = [&](uint64_t i) {
@@ -466,30 +676,101 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
             any = any || maybe[k];
         }
         if (__ballot(any) == 0ull) return;
+        bool in[4];
+        uint32_t st[4], pix[4];
+        unsigned long long pm[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            unsigned long long mm = __ballot(maybe[k]);
-            if (mm == 0ull) continue;
+            in[k] = false;
+            st[k] = 0;
+            pix[k] = 0;
+            pm[k] = 0ull;
+            if (__ballot(maybe[k]) == 0ull) continue;
             float inv = 1.0f / rz[k];                 // correctly rounded (contract option B)
             float fu = rintf(f_mul(rx[k], inv));      // render.cu:65
             float fv = rintf(f_mul(ry[k], inv));      // render.cu:66
-            bool in = maybe[k] && (fu >= 0.0f) && (fu < fW) && (fv >= 0.0f) && (fv < fH);  // render.cu:68
-            unsigned long long m = __ballot(in);
-            if (m == 0ull) continue;
-            if (in) {
-                int u = (int)fu, v = (int)fv;
-                uint32_t tile = (uint32_t)((v >> 5) * g.tiles_x + (u >> g.tw_shift));
-                uint32_t tiled = (tile << tshift) | (uint32_t)(((v & 31) << g.tw_shift) | (u & twm));
-                uint32_t pos = fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (!(dbg & 64)) {
-                    my_t[pos] = tiled;
-                    my_d[pos] = __float_as_uint(rz[k]);
-                    my_i[pos] = (uint32_t)(4 * i + k);
-                }
-                if (!(dbg & 128)) lds_hist_add(s_hist, tile, true);  // exec = the in-frustum lanes
+            in[k] = maybe[k] && (fu >= 0.0f) && (fu < fW) && (fv >= 0.0f) && (fv < fH);  // render.cu:68
+            pm[k] = __ballot(in[k]);
+            if (in[k]) {
+                const int u = (int)fu, v = (int)fv;
+                st[k] = (uint32_t)((v >> 4) * g.stx + (u >> 5));
+                pix[k] = (uint32_t)(((v & 15) << 5) | (u & 31));
             }
-            fill += (uint32_t)__popcll(m);
+        }
+        if ((pm[0] | pm[1] | pm[2] | pm[3]) == 0ull) return;
+        // the lane's four colours in one 16-byte load, issued before the claims return
+        uint4 col = make_uint4(0u, 0u, 0u, 0u);
+        if (in[0] || in[1] || in[2] || in[3]) col = rgba4[i];
+        // group by storage tile; group `it` is claimed by lane `it`
+        // (the claiming lane is the group's first lane: lanes past the end of the cloud are inactive here)
+        int grp[4] = {-1, -1, -1, -1};
+        uint32_t rank[4] = {0, 0, 0, 0};
+        uint32_t claim[kMaxGroups];
+        int leader[kMaxGroups];
+        int ng = 0;
+#pragma unroll
+        for (int it = 0; it < kMaxGroups; ++it) {
+            claim[it] = 0;
+            leader[it] = 0;
+            const int kk = pm[0] ? 0 : (pm[1] ? 1 : (pm[2] ? 2 : (pm[3] ? 3 : -1)));
+            if (kk < 0) continue;  // wave-uniform
+            const unsigned long long pk = kk == 0 ? pm[0] : (kk == 1 ? pm[1] : (kk == 2 ? pm[2] : pm[3]));
+            const uint32_t sk = kk == 0 ? st[0] : (kk == 1 ? st[1] : (kk == 2 ? st[2] : st[3]));
+            const int first = __ffsll((long long)pk) - 1;
+            const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)sk, first);
+            uint32_t total = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool gk = in[k] && grp[k] < 0 && st[k] == lead;
+                const unsigned long long m = __ballot(gk);
+                if (gk) {
+                    grp[k] = it;
+                    rank[k] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                }
+                total += (uint32_t)__popcll(m);
+                pm[k] &= ~m;
+            }
+            if (lane == first) claim[it] = atomicAdd(S.fill + lead, total);
+            leader[it] = first;
+            ng = it + 1;
+        }
+        // whatever is left belongs to a fourth, fifth, ... tile: one claim per point
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (in[k] && grp[k] < 0) {
+                rank[k] = atomicAdd(S.fill + st[k], 1u);
+                grp[k] = kMaxGroups;
+            }
+        uint32_t base[kMaxGroups];
+#pragma unroll
+        for (int it = 0; it < kMaxGroups; ++it)
+            base[it] = it < ng ? (uint32_t)__builtin_amdgcn_readlane((int)claim[it], leader[it]) : 0u;
+        const uint32_t cs[4] = {col.x, col.y, col.z, col.w};
+        uint32_t v[4];
+        bool dyn = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t b = 0;
+#pragma unroll
+            for (int it = 0; it < kMaxGroups; ++it) b = grp[k] == it ? base[it] : b;
+            v[k] = b + rank[k];
+            dyn = dyn || (in[k] && v[k] >= kS0);
+        }
+        if (__ballot(dyn) == 0ull) {  // the usual case: every position lies in its tile's static extent
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (in[k]) S.ext0[((size_t)st[k] << kS0Shift) + v[k]] = make_entry(__float_as_uint(rz[k]), pix[k], cs[k]);
+        } else {
+            unsigned long long own[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) own[k] = (in[k] && v[k] >= kS0) ? extent_alloc(S, st[k], v[k]) : 0ull;
+            __builtin_amdgcn_wave_barrier();  // every allocation of this wave is published before it polls
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (in[k]) {
+                    uint64_t *slot = v[k] < kS0 ? S.ext0 + ((size_t)st[k] << kS0Shift) + v[k] : extent_slot(S, st[k], v[k], own[k]);
+                    if (slot) *slot = make_entry(__float_as_uint(rz[k]), pix[k], cs[k]);
+                }
         }
     };
 
@@ -545,156 +826,20 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
             }
         }
     }
-    if (lane == 0) L.counts[gtid >> 6] = fill;
+    // every claim of this workgroup has returned (its value was used); the workgroup that takes the
+    // last ticket sees every stream length final
+    __shared__ uint32_t s_last;
     __syncthreads();
-    // the workgroup's histogram goes to the global one (contiguous atomics) and, as a dense
-    // row, to blk_hist: T3's workgroup of the same index sorts exactly these entries and
-    // needs the per-tile counts again
-    uint32_t *row = blk_hist + (size_t)blockIdx.x * g.ntiles;
-    for (int t = threadIdx.x; t < g.ntiles; t += kBlock) {
-        uint32_t c = s_hist[t];
-        row[t] = c;
-        if (c) atomicAdd(&tile_hist[t], c);
-    }
+    if (threadIdx.x == 0) s_last = atomicAdd(S.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (s_last) bin_epilogue(S, g, W, H, clear_split, depth, acc, occ);
 }
 
-// T2: exclusive scan of the histogram -> tile_start[0..ntiles], cursor[] = start, and the
-// histogram is re-zeroed for the next frame.  One workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *__restrict__ tile_hist, uint32_t *__restrict__ tile_start,
-                                                    uint32_t *__restrict__ cursor, uint32_t *__restrict__ order,
-                                                    uint32_t *__restrict__ stats, int ntiles,
-                                                    uint32_t *__restrict__ occ) {
-    __shared__ uint32_t s_w[16], s_m[16];
-    __shared__ uint32_t s_occ[128];  // tile occupancy bitmap for the peer-to-peer exchange (occ != NULL)
-    if (threadIdx.x < 128) s_occ[threadIdx.x] = 0;
-    __syncthreads();
-    const int per = (ntiles + 1023) / 1024;  // <= 4 (ntiles <= 4096)
-    const int lo = threadIdx.x * per;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t cnt[4] = {0, 0, 0, 0}, sum = 0;
-    for (int k = 0; k < per && k < 4; ++k)
-        if (lo + k < ntiles) {
-            cnt[k] = tile_hist[lo + k];
-            sum += cnt[k];
-        }
-    // inclusive scan over the workgroup (16 waves): shuffles inside a wave, one LDS hop across
-    // waves; `mx` rides along as a workgroup max.  Three barriers instead of the ~20 of a
-    // Hillis-Steele scan through LDS -- this kernel is pure latency on the frame's critical path.
-    auto scan = [&](uint32_t v, uint32_t &total, uint32_t &mx) -> uint32_t {
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(v, off, 64);
-            if (lane >= off) v += o;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const uint32_t o = __shfl_xor(mx, off, 64);
-            mx = o > mx ? o : mx;
-        }
-        if (lane == 63) s_w[wv] = v;
-        if (lane == 0) s_m[wv] = mx;
-        __syncthreads();
-        uint32_t base = 0;
-        total = 0;
-        mx = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {  // broadcast reads
-            const uint32_t wsum = s_w[k];
-            base += k < wv ? wsum : 0u;
-            total += wsum;
-            mx = s_m[k] > mx ? s_m[k] : mx;
-        }
-        __syncthreads();  // s_w / s_m are reused by the next scan
-        return v + base;
-    };
-    uint32_t total = 0, mx = 0;
-    for (int k = 0; k < per && k < 4; ++k) mx = cnt[k] > mx ? cnt[k] : mx;
-    uint32_t run = scan(sum, total, mx) - sum;  // exclusive prefix of this thread's chunk
-    for (int k = 0; k < per && k < 4; ++k)
-        if (lo + k < ntiles) {
-            tile_start[lo + k] = run;
-            cursor[lo + k] = run;
-            tile_hist[lo + k] = 0;
-            run += cnt[k];
-        }
-    if (threadIdx.x == 1023) tile_start[ntiles] = total;
-    if (occ) {
-        for (int k = 0; k < per && k < 4; ++k)
-            if (lo + k < ntiles && cnt[k]) atomicOr(&s_occ[(lo + k) >> 5], 1u << ((lo + k) & 31));
-        __syncthreads();
-        if (threadIdx.x < 128) occ[threadIdx.x] = s_occ[threadIdx.x];
-    }
-    // frame statistics for the host (mapped host memory, read without synchronisation): total
-    // entries and the entry count of the heaviest tile (one workgroup owns a whole tile in T4)
-    if (threadIdx.x == 0 && stats) {
-        stats[0] = total;
-        stats[1] = mx;
-    }
-    // launch order of the tile kernel: tiles with more than twice the mean entry count first,
-    // so the few heavy tiles that bound T4 start at once instead of trailing the launch
-    const uint32_t thr = 2u * (total / (uint32_t)ntiles) + 1u;
-    uint32_t heavy = 0;
-    for (int k = 0; k < per && k < 4; ++k) heavy += (lo + k < ntiles && cnt[k] > thr) ? 1u : 0u;
-    uint32_t n_heavy = 0, unused = 0;
-    uint32_t h_before = scan(heavy, n_heavy, unused) - heavy;
-    for (int k = 0; k < per && k < 4; ++k)
-        if (lo + k < ntiles) {
-            const bool h = cnt[k] > thr;
-            const uint32_t pos = h ? h_before : n_heavy + (uint32_t)(lo + k) - h_before;
-            order[pos] = (uint32_t)(lo + k);
-            h_before += h ? 1u : 0u;
-        }
-}
-
-// T3: counting sort by tile.  Workgroup b re-reads the four wave lists that workgroup b of
-// T1 wrote (same grid): count per tile in LDS (reads only the 4-byte keys), claim a
-// contiguous range per tile with one returning atomic, then move the entries (one 12-byte
-// store each).  Four entries per lane are in flight at a time: the loops are latency-bound.
-template <int WPR>  // waves per list region: the loops are latency chains, more waves shorten them
-__global__ __launch_bounds__(kBlock * WPR) void k_scatter(Lists L, int ntiles, int tshift,
-                                                          const uint32_t *__restrict__ blk_hist,
-                                                          uint32_t *__restrict__ cursor, Entry *__restrict__ binned,
-                                                          int dbg) {
-    constexpr int T = kBlock * WPR;
-    extern __shared__ uint32_t s_cnt[];  // running write positions per tile (after the claims)
-    const uint32_t *row = blk_hist + (size_t)blockIdx.x * ntiles;  // T1's counts for these entries
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint64_t region = (uint64_t)blockIdx.x * (kBlock / 64) + (w / WPR);
-    const uint32_t first = (uint32_t)(w % WPR) * 64 + lane, step = 64 * WPR;
-    const uint64_t base = region * L.region_cap;
-    const uint32_t *__restrict__ my_t = L.tiled + base, *__restrict__ my_d = L.depth + base,
-                                 *__restrict__ my_i = L.idx + base;
-    uint32_t cnt = L.counts[region];
-    if (dbg & 2) cnt = 0;
-    // claim this workgroup's run in every tile it touches; the returning atomics of four
-    // tiles are in flight together (their ~microsecond round trips would otherwise serialise)
-    for (int t0 = threadIdx.x; t0 < ntiles; t0 += 4 * T) {
-        uint32_t c[4], r[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) c[k] = (t0 + k * T < ntiles) ? row[t0 + k * T] : 0u;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = c[k] ? atomicAdd(&cursor[t0 + k * T], c[k]) : 0u;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (t0 + k * T < ntiles) s_cnt[t0 + k * T] = r[k];
-    }
-    __syncthreads();
-    for (uint32_t e = first; e < cnt; e += 4 * step) {
-        uint32_t t[4], d[4], ix[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            bool v = e + step * k < cnt;
-            t[k] = v ? my_t[e + step * k] : 0xFFFFFFFFu;
-            d[k] = v ? my_d[e + step * k] : 0u;
-            ix[k] = v ? my_i[e + step * k] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bool v = t[k] != 0xFFFFFFFFu;
-            uint32_t pos = lds_hist_add(s_cnt, t[k] >> tshift, v);
-            if (v) binned[pos] = Entry{t[k], d[k], ix[k]};
-        }
-    }
+// frames without points: the epilogue alone
+__global__ __launch_bounds__(kBlock) void k_bin_empty(int W, int H, TileGeom g, TileStore S, int clear_split,
+                                                      uint32_t *__restrict__ depth, uint32_t *__restrict__ acc,
+                                                      uint32_t *__restrict__ occ) {
+    bin_epilogue(S, g, W, H, clear_split, depth, acc, occ);
 }
 
 __device__ __forceinline__ float min2(float a, float b) { return a < b ? a : b; }  // project_cloud.cu:46-49
@@ -776,150 +921,173 @@ __device__ __forceinline__ void tile_pyramid(const uint32_t *s_depth, uint32_t *
     }
 }
 
+
 // T4: per-tile LDS z-buffer.  MODE 0 = whole frame (min + accumulate + resolve, writes
-// depth / image / optionally the accumulators); MODE 1 = min only (depth = min(depth,
+// depth / image / optionally the accumulators; for a split tile only the min phase), MODE 3 = the
+// second phase of the split tiles of a whole frame; MODE 1 = min only (depth = min(depth,
 // tile min): the phase call before the multi-GPU MIN all-reduce); MODE 2 = accumulate
 // only against the depth buffer in memory (acc += tile sums).
-// 512 threads and four entries in flight per thread: the heaviest tile (5-6 x the mean
-// entry count on the benchmark scenes) sets the launch time.
+// 512 threads and eight entries in flight per thread.  Work item = tile | slice << 12 |
+// (slices - 1) << 22 from T1's epilogue: an unsplit tile (one slice) is owned by one workgroup,
+// the slices of a split tile are merged through the frame buffers.
 template <int MODE>
-__global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__ binned,
-                                                        const uint32_t *__restrict__ tile_start,
-                                                        const uint32_t *__restrict__ order,
-                                                        const uint32_t *__restrict__ rgba, TileGeom g, int W, int H,
-                                                        float window, uint32_t *__restrict__ depth,
-                                                        uint32_t *__restrict__ acc, uint8_t *__restrict__ img,
-                                                        int write_acc, TilePyr pyr, Sliced dsl) {
+__global__ __launch_bounds__(kTileThreads) void k_tile(TileStore S, TileGeom g, int W, int H, float window,
+                                                        uint32_t *__restrict__ depth, uint32_t *__restrict__ acc,
+                                                        uint8_t *__restrict__ img, int write_acc, TilePyr pyr,
+                                                        Sliced dsl) {
     extern __shared__ uint32_t s_mem[];
+    __shared__ unsigned long long s_seg_p[kMaxSegs];
+    __shared__ uint32_t s_seg_n[kMaxSegs], s_seg_pb[kMaxSegs];
+    __shared__ uint32_t s_nseg, s_flag;
     const int tpix = 32 << g.tw_shift;  // pixels per tile
     uint32_t *s_depth = s_mem;          // [tpix]
     uint32_t *s_acc = s_mem + tpix;     // [4 * tpix]
-    uint8_t *s_rgb = reinterpret_cast<uint8_t *>(s_mem + 5 * tpix);  // [3 * tpix] (MODE 0)
-    const int tile = (int)order[blockIdx.x], tid = threadIdx.x;  // heavy tiles first (k_tile_scan)
-    const int tx0 = (tile % g.tiles_x) << g.tw_shift, ty0 = (tile / g.tiles_x) * kTileH;
-    const int tw = 1 << g.tw_shift, tmask = tpix - 1;
-    const uint32_t e0 = tile_start[tile];
-    uint32_t e1 = tile_start[tile + 1];
-    const int dbg = write_acc >> 8;
+    uint8_t *s_rgb = reinterpret_cast<uint8_t *>(s_mem + 5 * tpix);  // [3 * tpix] (MODE 0, 3)
+    const int tid = threadIdx.x;
+    constexpr uint32_t T = kTileThreads;
+    const int tw = 1 << g.tw_shift;
     // MODE 1 / 2, bit 1: this launch is the only writer of the frame buffer (no rtr_clear before it):
     // store the tile's depth / sums instead of folding them into what memory holds
     const bool overwrite = (write_acc & 2) != 0;
     write_acc &= 1;
-    constexpr uint32_t T = kTileThreads;
+    const uint32_t n_items = MODE == 3 ? S.hdr[kHdrSplitItems] : S.hdr[kHdrItems];
 
-    for (int p = tid; p < tpix; p += T) {
-        if (MODE == 2) {
-            int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
-            if (x < W && y < H) {
-                const size_t gp = (size_t)y * W + x;
-                if (dsl.chunk) {  // sharded frame: the global minimum still lies in the ranks' reduced slices
-                    const uint32_t v = static_cast<const uint32_t *>(dsl.src.p[gp / dsl.chunk])[gp];
-                    s_depth[p] = v;
-                    depth[gp] = v;  // ... and this launch is what completes RTR_BUF_DEPTH
+    for (uint32_t item_i = blockIdx.x; item_i < n_items; item_i += gridDim.x) {
+        const uint32_t item = S.items[item_i];
+        const int tile = (int)(item & 4095u);
+        const uint32_t sub = (item >> 12) & 1023u, nsub = (item >> 22) + 1u;
+        const bool split = nsub > 1u;
+        const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+        const int tx0 = tx << g.tw_shift, ty0 = ty * kTileH;
+        if (item_i != blockIdx.x) __syncthreads();  // the previous item's LDS is no longer read
+        if (tid == 0) s_nseg = 0;
+        __syncthreads();
+        // the contiguous pieces of this item's entries: per stream the static extent and the dynamic ones,
+        // clipped to the slice [sub, sub + 1) / nsub of the stream
+        if (tid < kMaxSegs) {
+            const int s = tid / kDirK, k = tid % kDirK;
+            const int st = s < (2 << (g.tw_shift - 5)) ? stream_tile(g, tx, ty, s) : -1;
+            if (st >= 0) {
+                const unsigned long long cnt = S.count[st];
+                const unsigned long long a = cnt * sub / nsub, b = cnt * (sub + 1u) / nsub;
+                const unsigned long long e_lo = k == 0 ? 0ull : ((unsigned long long)kS0 << (k - 1));
+                const unsigned long long e_hi = (unsigned long long)kS0 << k;
+                const unsigned long long lo = a > e_lo ? a : e_lo, hi = b < e_hi ? b : e_hi;
+                if (hi > lo) {
+                    const uint64_t *p = k == 0 ? S.ext0 + ((size_t)st << kS0Shift) + lo
+                                               : S.dyn + (S.dir[(size_t)st * kDirK + k] >> 24) + (lo - e_lo);
+                    const uint32_t q = atomicAdd(&s_nseg, 1u);
+                    s_seg_p[q] = (unsigned long long)p;
+                    s_seg_n[q] = (uint32_t)(hi - lo);
+                    const int per_row = 1 << (g.tw_shift - 5);
+                    s_seg_pb[q] = (uint32_t)(((s >> (g.tw_shift - 5)) * 16) * tw + (s & (per_row - 1)) * 32);
+                }
+            }
+        }
+        // depth tile
+        for (int p = tid; p < tpix; p += T) {
+            if (MODE >= 2) {
+                int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
+                if (x < W && y < H) {
+                    const size_t gp = (size_t)y * W + x;
+                    if (dsl.chunk) {  // sharded frame: the global minimum still lies in the ranks' reduced slices
+                        const uint32_t v = static_cast<const uint32_t *>(dsl.src.p[gp / dsl.chunk])[gp];
+                        s_depth[p] = v;
+                        if (sub == 0) depth[gp] = v;  // ... and this launch is what completes RTR_BUF_DEPTH
+                    } else {
+                        s_depth[p] = depth[gp];
+                    }
                 } else {
-                    s_depth[p] = depth[gp];
+                    s_depth[p] = RTR_EMPTY;
                 }
             } else {
                 s_depth[p] = RTR_EMPTY;
             }
-        } else {
-            s_depth[p] = RTR_EMPTY;
-        }
-    }
-    // Accumulators: the exact layout is two 64-bit words per pixel, (c0 | c1 << 32) and
-    // (c2 | count << 32).  LDS atomics are what bounds this kernel (about one lane per clock
-    // and CU), so tiles with <= 60000 entries first try ONE packed word per pixel and entry,
-    // c0 | c1 << 16 | c2 << 32 | count << 48: no 16-bit field can overflow while a pixel's
-    // count is <= 257 (255 * 257 = 65535), a carry can only move upwards inside the pixel's
-    // own word (so the count field never reads low), and the count cannot wrap below 65536
-    // entries.  If any pixel ends with count > 257 the whole tile is redone with the wide layout.
-    unsigned long long *s_acc64 = reinterpret_cast<unsigned long long *>(s_acc);
-    bool narrow = (MODE != 1) && (e1 - e0 <= 60000u);
-    if (MODE != 1)
-        for (int p = tid; p < (narrow ? 2 : 4) * tpix; p += T) s_acc[p] = 0;
-    __syncthreads();
-    if (MODE != 2 && !(dbg & 4)) {
-        for (uint32_t e = e0 + tid; e < e1; e += kTileBatch * T) {
-            uint32_t t[kTileBatch], d[kTileBatch];
-#pragma unroll
-            for (int k = 0; k < kTileBatch; ++k) {
-                uint32_t ee = e + k * T;
-                Entry r = (ee < e1) ? binned[ee] : Entry{0u, RTR_EMPTY, 0u};
-                t[k] = r.tiled;
-                d[k] = r.depth;
-            }
-#pragma unroll
-            for (int k = 0; k < kTileBatch; ++k) {  // render.cu:81, behind an early-z read: an LDS read
-                // costs a fraction of an LDS atomic, and only a few entries per pixel lower its minimum
-                uint32_t *slot = &s_depth[t[k] & tmask];
-                if ((dbg & 256) || d[k] < *reinterpret_cast<volatile uint32_t *>(slot)) atomicMin(slot, d[k]);
-            }
         }
         __syncthreads();
-    }
-    auto accumulate = [&](bool packed) {
-        for (uint32_t e = e0 + tid; e < e1; e += kTileBatch * T) {
-            uint32_t t[kTileBatch], d[kTileBatch], ix[kTileBatch];
+        const uint32_t nseg = s_nseg;
+        uint32_t n_local = 0;
+        for (uint32_t q = 0; q < nseg; ++q) n_local += s_seg_n[q];
+        const bool do_min = MODE == 1 || MODE == 0;
+        const bool do_acc = MODE >= 2 || (MODE == 0 && !split);
+        // Accumulators: the exact layout is two 64-bit words per pixel, (c0 | c1 << 32) and
+        // (c2 | count << 32).  LDS atomics are what bounds this kernel (about one lane per clock
+        // and CU), so items with <= 60000 entries first try ONE packed word per pixel and entry,
+        // c0 | c1 << 16 | c2 << 32 | count << 48: no 16-bit field can overflow while a pixel's
+        // count is <= 257 (255 * 257 = 65535), a carry can only move upwards inside the pixel's
+        // own word (so the count field never reads low), and the count cannot wrap below 65536
+        // entries.  If any pixel ends with count > 257 the whole item is redone with the wide layout.
+        unsigned long long *s_acc64 = reinterpret_cast<unsigned long long *>(s_acc);
+        bool narrow = do_acc && (n_local <= 60000u);
+        if (do_acc)
+            for (int p = tid; p < (narrow ? 2 : 4) * tpix; p += T) s_acc[p] = 0;
+        if (do_min) {
+            for (uint32_t q = 0; q < nseg; ++q) {
+                const unsigned long long *ent = reinterpret_cast<const unsigned long long *>(s_seg_p[q]);
+                const uint32_t n = s_seg_n[q], pb = s_seg_pb[q];
+                for (uint32_t e = tid; e < n; e += kTileBatch * T) {
+                    unsigned long long r[kTileBatch];
 #pragma unroll
-            for (int k = 0; k < kTileBatch; ++k) {
-                uint32_t ee = e + k * T;
-                Entry r = (ee < e1) ? binned[ee] : Entry{0u, 0x7F800000u, 0u};  // +inf fails every window test
-                t[k] = r.tiled;
-                d[k] = r.depth;
-                ix[k] = r.idx;
-            }
-            bool hit[kTileBatch];
-            uint32_t c[kTileBatch];
+                    for (int k = 0; k < kTileBatch; ++k) {
+                        const uint32_t ee = e + k * T;
+                        r[k] = (ee < n) ? ent[ee] : ((unsigned long long)RTR_EMPTY << 33);
+                    }
 #pragma unroll
-            for (int k = 0; k < kTileBatch; ++k) {
-                float m = __uint_as_float(s_depth[t[k] & tmask]);
-                hit[k] = !(__uint_as_float(d[k]) > f_add(m, window));  // render.cu:106
-                c[k] = hit[k] ? ((dbg & 32) ? ix[k] : rgba[ix[k]]) : 0u;  // dbg 32: timing experiment, no colour gather
-            }
-#pragma unroll
-            for (int k = 0; k < kTileBatch; ++k)
-                if (hit[k]) {  // render.cu:125-128
-                    const unsigned long long c0 = c[k] & 0xFFu, c1 = (c[k] >> 8) & 0xFFu, c2 = (c[k] >> 16) & 0xFFu;
-                    if (packed) {
-                        atomicAdd(s_acc64 + (t[k] & tmask), c0 | (c1 << 16) | (c2 << 32) | (1ull << 48));
-                    } else {
-                        atomicAdd(s_acc64 + 2 * (t[k] & tmask) + 0, c0 | (c1 << 32));
-                        atomicAdd(s_acc64 + 2 * (t[k] & tmask) + 1, c2 | (1ull << 32));
+                    for (int k = 0; k < kTileBatch; ++k) {  // render.cu:81, behind an early-z read: an LDS read
+                        // costs a fraction of an LDS atomic, and only a few entries per pixel lower its minimum
+                        const uint32_t d = (uint32_t)(r[k] >> 33), px = (uint32_t)(r[k] >> 24) & 511u;
+                        uint32_t *slot = &s_depth[pb + ((px >> 5) << g.tw_shift) + (px & 31u)];
+                        if (d < *reinterpret_cast<volatile uint32_t *>(slot)) atomicMin(slot, d);
                     }
                 }
+            }
         }
-    };
-    if (MODE != 1 && !(dbg & 8)) {
-        accumulate(narrow);
         __syncthreads();
-        if (narrow) {
-            int over = 0;
-            for (int p = tid; p < tpix; p += T) over |= (s_acc64[p] >> 48) > 257ull;
-            if (__syncthreads_or(over)) {  // rare: some pixel blends more than 257 points
-                narrow = false;
-                for (int p = tid; p < 4 * tpix; p += T) s_acc[p] = 0;
-                __syncthreads();
-                accumulate(false);
-                __syncthreads();
+        auto accumulate = [&](bool packed) {
+            for (uint32_t q = 0; q < nseg; ++q) {
+                const unsigned long long *ent = reinterpret_cast<const unsigned long long *>(s_seg_p[q]);
+                const uint32_t n = s_seg_n[q], pb = s_seg_pb[q];
+                for (uint32_t e = tid; e < n; e += kTileBatch * T) {
+                    unsigned long long r[kTileBatch];
+#pragma unroll
+                    for (int k = 0; k < kTileBatch; ++k) {
+                        const uint32_t ee = e + k * T;
+                        r[k] = (ee < n) ? ent[ee] : (0x7F800000ull << 33);  // +inf fails every window test
+                    }
+#pragma unroll
+                    for (int k = 0; k < kTileBatch; ++k) {
+                        const uint32_t d = (uint32_t)(r[k] >> 33), px = (uint32_t)(r[k] >> 24) & 511u;
+                        const uint32_t p = pb + ((px >> 5) << g.tw_shift) + (px & 31u);
+                        const float m = __uint_as_float(s_depth[p]);
+                        if (!(__uint_as_float(d) > f_add(m, window))) {  // render.cu:106, then :125-128
+                            const unsigned long long c0 = r[k] & 0xFFull, c1 = (r[k] >> 8) & 0xFFull, c2 = (r[k] >> 16) & 0xFFull;
+                            if (packed) {
+                                atomicAdd(s_acc64 + p, c0 | (c1 << 16) | (c2 << 32) | (1ull << 48));
+                            } else {
+                                atomicAdd(s_acc64 + 2 * p + 0, c0 | (c1 << 32));
+                                atomicAdd(s_acc64 + 2 * p + 1, c2 | (1ull << 32));
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        if (do_acc) {
+            accumulate(narrow);
+            __syncthreads();
+            if (narrow) {
+                int over = 0;
+                for (int p = tid; p < tpix; p += T) over |= (s_acc64[p] >> 48) > 257ull;
+                if (__syncthreads_or(over)) {  // rare: some pixel blends more than 257 points
+                    narrow = false;
+                    for (int p = tid; p < 4 * tpix; p += T) s_acc[p] = 0;
+                    __syncthreads();
+                    accumulate(false);
+                    __syncthreads();
+                }
             }
         }
-    }
-    // write-out: rows of the tile are contiguous in memory
-    if ((dbg & 16) && !pyr.enable) return;
-    for (int p = tid; p < tpix; p += T) {
-        int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
-        bool inb = x < W && y < H;
-        size_t gp = (size_t)y * W + x;
-        if (MODE == 0) {
-            if (inb) depth[gp] = s_depth[p];
-        } else if (MODE == 1) {
-            if (inb) {
-                const uint32_t v = s_depth[p];
-                if (overwrite || v < depth[gp]) depth[gp] = v;
-            }
-        }
-        if (MODE != 1) {
-            uint32_t a0, a1, a2, c;
+        auto sums_of = [&](int p, uint32_t &a0, uint32_t &a1, uint32_t &a2, uint32_t &c) {
             if (narrow) {
                 const unsigned long long pk = s_acc64[p];
                 a0 = (uint32_t)(pk & 0xFFFFu);
@@ -929,59 +1097,129 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const Entry *__restrict__
             } else {
                 a0 = s_acc[4 * p], a1 = s_acc[4 * p + 1], a2 = s_acc[4 * p + 2], c = s_acc[4 * p + 3];
             }
-            if (MODE == 2) {
-                if (inb) {
-                    uint4 o = overwrite ? make_uint4(0u, 0u, 0u, 0u) : reinterpret_cast<uint4 *>(acc)[gp];
-                    reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(o.x + a0, o.y + a1, o.z + a2, o.w + c);
+        };
+        bool finish = !split;  // this workgroup resolves / writes the image rows and emits the pyramid
+        if (split) {
+            // the slices of a split tile meet in the frame buffers, which hold the sentinel / zero (or what
+            // the caller's rtr_clear and earlier passes left there)
+            for (int p = tid; p < tpix; p += T) {
+                const int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
+                if (!(x < W && y < H)) continue;
+                const size_t gp = (size_t)y * W + x;
+                if (do_min) {
+                    const uint32_t v = s_depth[p];
+                    if (v != RTR_EMPTY && v < ld_fresh(depth + gp)) atomicMin(depth + gp, v);
+                } else {
+                    uint32_t a0, a1, a2, c;
+                    sums_of(p, a0, a1, a2, c);
+                    if (c) {
+                        unsigned long long *a = reinterpret_cast<unsigned long long *>(acc) + 2 * gp;
+                        atomicAdd(a + 0, (unsigned long long)a0 | ((unsigned long long)a1 << 32));
+                        atomicAdd(a + 1, (unsigned long long)a2 | ((unsigned long long)c << 32));
+                    }
+                }
+            }
+            if (MODE == 3) {  // the last slice to arrive resolves the tile from the summed accumulators
+                __threadfence();
+                __syncthreads();
+                if (tid == 0) s_flag = atomicAdd(S.hctr + tile, 1u) == nsub - 1u ? 1u : 0u;
+                __syncthreads();
+                finish = s_flag != 0u;
+                if (finish) {
+                    __threadfence();
+                    narrow = false;
+                    for (int p = tid; p < tpix; p += T) {
+                        const int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
+                        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                        if (x < W && y < H) {
+                            const unsigned long long *a = reinterpret_cast<const unsigned long long *>(acc) + 2 * ((size_t)y * W + x);
+                            const unsigned long long lo = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const unsigned long long hi = __hip_atomic_load(a + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            v = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+                        }
+                        reinterpret_cast<uint4 *>(s_acc)[p] = v;
+                    }
+                    __syncthreads();
+                }
+            } else if (MODE == 2) {
+                finish = sub == 0;  // only for the pyramid below (from the global depth tile every slice loaded)
+            }
+        }
+        // write-out: rows of the tile are contiguous in memory
+        if (!split || (MODE == 3 && finish)) {
+            for (int p = tid; p < tpix; p += T) {
+                int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
+                bool inb = x < W && y < H;
+                size_t gp = (size_t)y * W + x;
+                if (MODE == 0) {
+                    if (inb) depth[gp] = s_depth[p];
+                } else if (MODE == 1) {
+                    if (inb) {
+                        const uint32_t v = s_depth[p];
+                        if (overwrite || v < depth[gp]) depth[gp] = v;
+                    }
+                }
+                if (MODE != 1) {
+                    uint32_t a0, a1, a2, c;
+                    sums_of(p, a0, a1, a2, c);
+                    if (MODE == 2) {
+                        if (inb) {
+                            uint4 o = overwrite ? make_uint4(0u, 0u, 0u, 0u) : reinterpret_cast<uint4 *>(acc)[gp];
+                            reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(o.x + a0, o.y + a1, o.z + a2, o.w + c);
+                        }
+                    } else {
+                        if (MODE == 0 && inb && write_acc) reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(a0, a1, a2, c);
+                        s_rgb[3 * p + 0] = c ? (uint8_t)(a0 / c) : 0;  // render.cu:147-162
+                        s_rgb[3 * p + 1] = c ? (uint8_t)(a1 / c) : 0;
+                        s_rgb[3 * p + 2] = c ? (uint8_t)(a2 / c) : 0;
+                    }
+                }
+            }
+        }
+        if ((MODE == 0 && !split) || (MODE == 3 && finish)) {
+            __syncthreads();
+            // image rows of the tile as dwords when the row segment is whole and 4-byte aligned
+            const int row_dw = (3 * tw) >> 2;  // 24 or 48 dwords per tile row
+            const bool fast = (tx0 + tw <= W) && ((W & 3) == 0);
+            if (fast) {
+                const uint32_t *s_rgb32 = reinterpret_cast<const uint32_t *>(s_rgb);
+                for (int q = tid; q < row_dw * kTileH; q += T) {
+                    int r = q / row_dw, dw = q - r * row_dw, y = ty0 + r;
+                    if (y < H) reinterpret_cast<uint32_t *>(img + ((size_t)y * W + tx0) * 3)[dw] = s_rgb32[r * row_dw + dw];
                 }
             } else {
-                if (inb && write_acc) reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(a0, a1, a2, c);
-                s_rgb[3 * p + 0] = c ? (uint8_t)(a0 / c) : 0;  // render.cu:147-162
-                s_rgb[3 * p + 1] = c ? (uint8_t)(a1 / c) : 0;
-                s_rgb[3 * p + 2] = c ? (uint8_t)(a2 / c) : 0;
+                for (int q = tid; q < 3 * tpix; q += T) {
+                    int p = q / 3, ch = q - 3 * p;
+                    int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
+                    if (x < W && y < H) img[((size_t)y * W + x) * 3 + ch] = s_rgb[q];
+                }
             }
+            if (pyr.enable)  // s_acc is free now (the colours were resolved into s_rgb before the barrier)
+                tile_pyramid(s_depth, s_acc, g, tx0, ty0, pyr.L, pyr.n_eff_rows, pyr.part_min, pyr.part_max, tile, tid, T);
         }
-    }
-    if (MODE == 0) {
-        __syncthreads();
-        // image rows of the tile as dwords when the row segment is whole and 4-byte aligned
-        const int row_dw = (3 * tw) >> 2;  // 24 or 48 dwords per tile row
-        const bool fast = (tx0 + tw <= W) && ((W & 3) == 0);
-        if (fast) {
-            const uint32_t *s_rgb32 = reinterpret_cast<const uint32_t *>(s_rgb);
-            for (int q = tid; q < row_dw * kTileH; q += T) {
-                int r = q / row_dw, dw = q - r * row_dw, y = ty0 + r;
-                if (y < H) reinterpret_cast<uint32_t *>(img + ((size_t)y * W + tx0) * 3)[dw] = s_rgb32[r * row_dw + dw];
-            }
-        } else {
-            for (int q = tid; q < 3 * tpix; q += T) {
-                int p = q / 3, ch = q - 3 * p;
-                int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
-                if (x < W && y < H) img[((size_t)y * W + x) * 3 + ch] = s_rgb[q];
-            }
-        }
-        if (pyr.enable)  // s_acc is free now (the colours were resolved into s_rgb before the barrier)
+        if (MODE == 2 && pyr.enable && finish) {  // sharded frames: s_depth holds the GLOBAL minimum of the tile here
+            __syncthreads();                      // the sums have been read out of s_acc
             tile_pyramid(s_depth, s_acc, g, tx0, ty0, pyr.L, pyr.n_eff_rows, pyr.part_min, pyr.part_max, tile, tid, T);
-    }
-    if (MODE == 2 && pyr.enable) {  // sharded frames: s_depth holds the GLOBAL minimum of the tile here
-        __syncthreads();            // the sums have been read out of s_acc
-        tile_pyramid(s_depth, s_acc, g, tx0, ty0, pyr.L, pyr.n_eff_rows, pyr.part_min, pyr.part_max, tile, tid, T);
+        }
     }
 }
 
-void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const Lists &L,
-                        uint32_t *tile_hist, uint32_t *blk_hist, const float *bounds) {
+void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const TileStore &S,
+                        const float *bounds, int clear_split, uint32_t *depth, uint32_t *acc, uint32_t *occ) {
     TileGeom g = tile_geom(W, H);
     uint64_t n4 = (c.n + 3) / 4;
-    if (n4 == 0) return;
+    if (n4 == 0) {
+        hipLaunchKernelGGL(k_bin_empty, dim3(1), dim3(kBlock), 0, s, W, H, g, S, clear_split, depth, acc, occ);
+        return;
+    }
     if (bounds)
-        hipLaunchKernelGGL(k_project_bin<true>, dim3(point_grid(n4, c.grid)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s,
-                           (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, g, L, tile_hist,
-                           blk_hist, bounds, c.debug);
+        hipLaunchKernelGGL(k_project_bin<true>, dim3(point_grid(n4, c.grid)), dim3(kBlock), 0, s, (const float4 *)c.x,
+                           (const float4 *)c.y, (const float4 *)c.z, (const uint4 *)c.rgba, n4, P, W, H, g, S, bounds,
+                           clear_split, depth, acc, occ);
     else
-        hipLaunchKernelGGL(k_project_bin<false>, dim3(point_grid(n4, c.grid)), dim3(kBlock), g.ntiles * sizeof(uint32_t), s,
-                           (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, P, W, H, g, L, tile_hist,
-                           blk_hist, bounds, c.debug);
+        hipLaunchKernelGGL(k_project_bin<false>, dim3(point_grid(n4, c.grid)), dim3(kBlock), 0, s, (const float4 *)c.x,
+                           (const float4 *)c.y, (const float4 *)c.z, (const uint4 *)c.rgba, n4, P, W, H, g, S, bounds,
+                           clear_split, depth, acc, occ);
 }
 
 // bounding box of every 256-point chunk (the unit one wave of T1 handles per iteration):
@@ -1028,38 +1266,28 @@ void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds) {
                        (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, bounds);
 }
 
-void launch_bin_sort(hipStream_t s, const Cloud &c, int W, int H, const Lists &L, const Bins &B, uint32_t *occ) {
-    TileGeom g = tile_geom(W, H);
-    uint64_t n4 = (c.n + 3) / 4;
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, B.tile_hist, B.tile_start, B.cursor, B.order, B.stats,
-                       g.ntiles, occ);
-    if (n4 == 0) return;
-    hipLaunchKernelGGL(k_scatter<kScatterWPR>, dim3(point_grid(n4, c.grid)), dim3(kBlock * kScatterWPR),
-                       g.ntiles * sizeof(uint32_t), s, L, g.ntiles, g.tw_shift + 5, B.blk_hist, B.cursor, B.entries,
-                       c.debug & 3);
-}
 
-void launch_tile(hipStream_t s, int mode, const Cloud &c, int W, int H, const Bins &B, float window, uint32_t *depth,
+void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, float window, uint32_t *depth,
                  uint32_t *acc, uint8_t *img, int write_acc, const TilePyr *pyr, const Sliced *depth_slices) {
     TileGeom g = tile_geom(W, H);
     Sliced nosl{};
     nosl.chunk = 0;
     size_t tpix = (size_t)32 << g.tw_shift;
-    size_t lds = (mode == 1 ? tpix : 5 * tpix) * sizeof(uint32_t) + (mode == 0 ? 3 * tpix : 0);
+    size_t lds = (mode == 1 ? tpix : 5 * tpix) * sizeof(uint32_t) + ((mode == 0 || mode == 3) ? 3 * tpix : 0);
     TilePyr none{};
     none.enable = 0;
+    const dim3 grid(g.ntiles + kHeavyExtra), block(kTileThreads);
     if (mode == 0)
-        hipLaunchKernelGGL(k_tile<0>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, B.order, c.rgba, g,
-                           W,
-                           H, window, depth, acc, img, write_acc | ((c.debug >> 2) << 10), pyr ? *pyr : none, nosl);
+        hipLaunchKernelGGL(k_tile<0>, grid, block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 1,
+                           pyr ? *pyr : none, nosl);
+    else if (mode == 3)  // only the split tiles' slices: all of these workgroups leave at once on ordinary frames
+        hipLaunchKernelGGL(k_tile<3>, dim3(kHeavyExtra), block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 1,
+                           pyr ? *pyr : none, nosl);
     else if (mode == 1)
-        hipLaunchKernelGGL(k_tile<1>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, B.order, c.rgba, g,
-                           W,
-                           H, window, depth, acc, img, write_acc & 2, none, nosl);
+        hipLaunchKernelGGL(k_tile<1>, grid, block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 2, none, nosl);
     else  // mode 2 always writes the accumulators; bit 1 of write_acc = overwrite; pyr: also emit the pyramid
-        hipLaunchKernelGGL(k_tile<2>, dim3(g.ntiles), dim3(kTileThreads), lds, s, B.entries, B.tile_start, B.order, c.rgba, g,
-                           W,
-                           H, window, depth, acc, img, 1 | (write_acc & 2), pyr ? *pyr : none, depth_slices ? *depth_slices : nosl);
+        hipLaunchKernelGGL(k_tile<2>, grid, block, lds, s, S, g, W, H, window, depth, acc, img, 1 | (write_acc & 2),
+                           pyr ? *pyr : none, depth_slices ? *depth_slices : nosl);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1652,12 +1880,12 @@ __global__ void k_p2p_sync(uint32_t *__restrict__ my_flags, PeerSet peer_flags, 
 // tile t; all ones when a rank's frame did not come from the bins.
 constexpr int kOccWords = 128;  // 4096 tiles
 
-__global__ void k_p2p_occupancy(const uint32_t *__restrict__ tile_start, int ntiles, uint32_t *__restrict__ occ) {
+__global__ void k_p2p_occupancy(const uint32_t *__restrict__ tile_cnt, int ntiles, uint32_t *__restrict__ occ) {
     const int w = threadIdx.x;  // one 32-tile word per thread, kOccWords threads
     uint32_t bits = 0;
     for (int b = 0; b < 32; ++b) {
         const int t = 32 * w + b;
-        if (tile_start == nullptr || (t < ntiles && tile_start[t + 1] > tile_start[t])) bits |= 1u << b;
+        if (tile_cnt == nullptr || (t < ntiles && tile_cnt[t] != 0u)) bits |= 1u << b;
     }
     occ[w] = bits;
 }
@@ -1765,9 +1993,9 @@ void launch_p2p_sync(hipStream_t s, uint32_t *my_flags, const PeerSet &peer_flag
                      uint32_t *status, unsigned long long timeout_ticks) {
     hipLaunchKernelGGL(k_p2p_sync, dim3(1), dim3(64), 0, s, my_flags, peer_flags, rank, world, seq, status, timeout_ticks);
 }
-// tile_start == NULL: every tile counts as occupied (the frame did not come from the bins)
-void launch_p2p_occupancy(hipStream_t s, const uint32_t *tile_start, int W, int H, uint32_t *occ) {
-    hipLaunchKernelGGL(k_p2p_occupancy, dim3(1), dim3(kOccWords), 0, s, tile_start, tile_count(W, H), occ);
+// tile_cnt == NULL: every tile counts as occupied (the frame did not come from the bins)
+void launch_p2p_occupancy(hipStream_t s, const uint32_t *tile_cnt, int W, int H, uint32_t *occ) {
+    hipLaunchKernelGGL(k_p2p_occupancy, dim3(1), dim3(kOccWords), 0, s, tile_cnt, tile_count(W, H), occ);
 }
 void launch_p2p_depth_reduce(hipStream_t s, const PeerSet &depth, const PeerSet &occ, uint32_t *red, size_t first,
                              size_t count, int world, int W, int H) {

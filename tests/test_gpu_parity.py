@@ -35,12 +35,19 @@ def _check_frame(pkg, orc, projector, xyzw, rgba, P, W, H, filtered=True):
     return ref
 
 
-@pytest.fixture(params=[1, 0], ids=["tile", "two-pass"])
+@pytest.fixture(params=[1, 2, 0], ids=["tile", "tile-split", "two-pass"])
 def mode(request, projector):
-    projector.set_option("mode", request.param)
+    """tile-split: the binned form with the split threshold lowered to 64 entries, so that every
+    non-trivial tile of an ordinary test frame takes the several-workgroups-per-tile path."""
+    projector.set_option("mode", 1 if request.param else 0)
+    if request.param == 2:
+        projector.set_option("split_threshold", 64)
+        projector.set_option("split_slice", 48)
     projector.set_option("keep_accum", 1)
     yield request.param
     projector.set_option("mode", 1)
+    projector.set_option("split_threshold", 32768)
+    projector.set_option("split_slice", 16384)
     projector.set_option("keep_accum", 0)
 
 
@@ -303,8 +310,8 @@ def test_frames_larger_than_4k_fall_back(pkg, orc, projector):
 
 
 def test_point_grid_is_per_context(pkg, orc, projector):
-    """The tuning knob "point_grid" sizes a context's candidate lists; changing it on one
-    context must not disturb another (it used to be process-wide)."""
+    """The tuning knob "point_grid" belongs to a context; changing it on one context must not
+    disturb another (it used to be process-wide)."""
     n, W, H = 300_000, 640, 480
     xyzw, rgba = orc.generate("room_shell", 12, 0, n, n)
     P = pkg.orbit_projection(9, W, H)
@@ -369,11 +376,10 @@ def test_auto_reorder_option(pkg, orc):
         p.close()
 
 
-def test_hot_tile_fallback_sequence(pkg, orc, projector):
-    """A run of frames whose points all fall into one tile: after the first such frame the library
-    switches whole-frame renders to the atomic form (steered by un-synchronised statistics from
-    the scan kernel) and probes the binned form every 16th frame; every frame stays exact, and
-    so does the return to an ordinary view."""
+def test_hot_tile_is_split_in_the_binned_form(pkg, orc, projector):
+    """A run of frames whose points all fall into one tile: the binned form stays in use (no
+    fallback to the atomic form), the tile is split over several workgroups, every frame stays
+    exact, and so does the return to an ordinary view."""
     rng = np.random.default_rng(31)
     n = 400_000
     xyz = np.stack([rng.uniform(-0.05, 0.05, n), rng.uniform(-0.05, 0.05, n), rng.uniform(1.9, 2.1, n)], axis=1)
@@ -385,13 +391,43 @@ def test_hot_tile_fallback_sequence(pkg, orc, projector):
     projector.upload_points(xyzw, rgba)
     projector.set_resolution(64, 48)
     refs = {id(P): orc.project(xyzw, rgba, P, 64, 48) for P in (P_hot, P_wide)}
-    for k in range(40):
-        P = P_hot if k < 34 else P_wide
-        img, depth = projector.project(P)
-        projector.synchronize()
+    for k in range(12):
+        P = P_hot if k < 8 else P_wide
+        filtered = bool(k & 1)
+        img, depth = projector.project(P, filtered=filtered)
+        st = projector.frame_stats()
+        assert st["errors"] == 0
+        if P is P_hot:
+            assert st["entries"] == n and st["heaviest_tile"] > n // 4 and st["split_tiles"] >= 1 \
+                and st["split_items"] >= 12, st
         ref = refs[id(P)]
-        assert np.array_equal(depth.view(np.uint32), ref["depth_bits"]), k
-        assert np.array_equal(img, ref["img"]), k
+        rd, ri = ref["depth_bits"], ref["img"]
+        if filtered:
+            rf = orc.filter(rd, ri)
+            rd, ri = rf["depth"].view(np.uint32), rf["img"]
+            assert np.array_equal(projector.download(pkg._lib.BUF_TENSOR).reshape(5, 48, 64), rf["tensor"]), k
+        assert np.array_equal(depth.view(np.uint32), rd), k
+        assert np.array_equal(img, ri), k
+
+
+def test_ten_million_points_in_one_tile(pkg, orc, projector):
+    """1e7 points inside one 32x32 tile (a distant overview): the tile kernel splits the tile over
+    hundreds of workgroups; depth, image, accumulators and the filtered outputs against the oracle."""
+    n, W, H = 10_000_000, 640, 480
+    rng = np.random.default_rng(77)
+    xyz = np.stack([rng.uniform(-0.3, 0.3, n), rng.uniform(-0.3, 0.3, n), rng.uniform(39.0, 41.0, n)], axis=1)
+    rgb = rng.integers(0, 256, size=(n, 3), dtype=np.uint8)
+    xyzw, rgba = cloud(xyz.astype(np.float32), rgb)
+    K = np.array([[512.0, 0, 336.0], [0, 512.0, 240.0], [0, 0, 1.0]])  # ~8 px wide blob inside tile (10, 7)
+    P = orc.compose_projection(K, np.eye(4))
+    projector.set_option("keep_accum", 1)
+    try:
+        ref = _check_frame(pkg, orc, projector, xyzw, rgba, P, W, H)
+    finally:
+        projector.set_option("keep_accum", 0)
+    st = projector.frame_stats()
+    assert st["errors"] == 0 and st["entries"] == n and st["heaviest_tile"] == n and st["split_items"] >= 256, st
+    assert int(ref["acc"][..., 3].sum()) > 0
 
 
 @pytest.mark.parametrize("tail_cus", [0, 8])
