@@ -9,6 +9,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librtr_hip.so")
+if os.environ.get("RTR_LIB_VARIANT"):  # e.g. "xp": the timing-experiment build (`make -C csrc experiment`)
+    LIB_PATH = os.path.join(_HERE, "lib", "librtr_hip_%s.so" % os.environ["RTR_LIB_VARIANT"])
 CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol include/rtr.h declares (tests check the library exports all of them)

@@ -47,6 +47,9 @@ struct rtr_ctx {
         rtr::TileStore store{};
         uint64_t pool_n = 0;        // point count the dynamic extent pool was sized for
         int nst = 0, ntiles = 0;    // tile counts the per-tile arrays were sized for
+        rtr::StoreConsts consts{};  // host copy of the store's header constants
+        uint64_t *dyn = nullptr;    // dynamic extent pool
+        uint64_t dyn_cap = 0;
         hipEvent_t binned = nullptr, consumed = nullptr;  // T1 done (front stream) / T4 done (tail stream)
         bool consumed_valid = false;
     } fs[2];
@@ -64,6 +67,9 @@ struct rtr_ctx {
     bool force_atomic = false;       // set around a whole frame that takes the atomic form (> 4096 tiles)
     int opt_heavy = 32768;           // tiles with more entries are split over several workgroups in T4 ...
     int opt_slice = 16384;           // ... into slices of at least this many entries
+    int opt_fill_shift = 5;          // stream counters 2^5 words = 128 B apart (see "fill_shift")
+    int opt_xp = 0;                  // RTR_EXPERIMENT builds only (tools/kbench.py)
+    int opt_phases = 1;         // T1: phase groups of the grid stride (option "phases", see k_project_bin)
     int opt_probe = 0;          // rtr_stream_probe variant (experiments)
     int opt_cull = 0;           // per-chunk frustum culling in T1
     int opt_auto_reorder = 0;   // Morton-sort every cloud right after upload / generation
@@ -176,10 +182,9 @@ void free_frame(rtr_ctx *c) {
     dfree(c->depth); dfree(c->acc); dfree(c->img); dfree(c->mask); dfree(c->part_min); dfree(c->part_max); dfree(c->tensor);
     for (int i = 1; i <= 8; ++i) dfree(c->lv.lv[i]);
     for (auto &f : c->fs) {
-        auto &t = f.store;
-        dfree(t.ext0); dfree(t.dir); dfree(t.fill); dfree(t.count); dfree(t.tile_cnt); dfree(t.items); dfree(t.hdr);
-        dfree(t.hctr); dfree(t.ticket); dfree(t.pool_next);
+        dfree(f.store.ext0); dfree(f.store.meta);
         f.nst = f.ntiles = 0;
+        f.consts = rtr::StoreConsts{};
     }
     c->lv.lv[0] = nullptr;
     c->W = c->H = 0;
@@ -188,8 +193,8 @@ void free_frame(rtr_ctx *c) {
 
 void free_lists(rtr_ctx *c) {  // the dynamic extent pools (sized by the point count)
     for (auto &f : c->fs) {
-        dfree(f.store.dyn);
-        f.store.dyn_cap = 0;
+        dfree(f.dyn);
+        f.dyn_cap = 0;
         f.pool_n = 0;
     }
     c->list_valid = false;
@@ -207,33 +212,30 @@ int ensure_tiles(rtr_ctx *c, hipStream_t s) {
     const int nt = rtr::tile_count(c->W, c->H), nst = rtr::storage_tile_count(c->W, c->H);
     auto &f = c->F();
     auto &t = f.store;
-    if (t.ext0 && f.nst == nst && f.ntiles == nt) return RTR_OK;
-    dfree(t.ext0); dfree(t.dir); dfree(t.fill); dfree(t.count); dfree(t.tile_cnt); dfree(t.items); dfree(t.hdr);
-    dfree(t.hctr); dfree(t.ticket); dfree(t.pool_next);
-    f.nst = f.ntiles = 0;
-    c->list_valid = false;
-    const size_t dir_bytes = (size_t)nst * rtr::kDirK * sizeof(unsigned long long);
-    HIP_TRY(c, hipMalloc((void **)&t.ext0, (size_t)nst * rtr::kS0 * sizeof(uint64_t)));
-    HIP_TRY(c, hipMalloc((void **)&t.dir, dir_bytes));
-    HIP_TRY(c, hipMalloc((void **)&t.fill, (size_t)nst * 4));
-    HIP_TRY(c, hipMalloc((void **)&t.count, (size_t)nst * 4));
-    HIP_TRY(c, hipMalloc((void **)&t.tile_cnt, (size_t)nt * 4));
-    HIP_TRY(c, hipMalloc((void **)&t.items, (size_t)(nt + rtr::kHeavyExtra + 16) * 4));
-    HIP_TRY(c, hipMalloc((void **)&t.hdr, 16 * 4));
-    HIP_TRY(c, hipMalloc((void **)&t.hctr, (size_t)nt * 4));
-    HIP_TRY(c, hipMalloc((void **)&t.ticket, 4));
-    HIP_TRY(c, hipMalloc((void **)&t.pool_next, 8));
-    HIP_TRY(c, hipMemsetAsync(t.dir, 0, dir_bytes, s));  // stamp 0 is never current
-    HIP_TRY(c, hipMemsetAsync(t.fill, 0, (size_t)nst * 4, s));
-    HIP_TRY(c, hipMemsetAsync(t.count, 0, (size_t)nst * 4, s));
-    HIP_TRY(c, hipMemsetAsync(t.tile_cnt, 0, (size_t)nt * 4, s));
-    HIP_TRY(c, hipMemsetAsync(t.hdr, 0, 16 * 4, s));
-    HIP_TRY(c, hipMemsetAsync(t.hctr, 0, (size_t)nt * 4, s));
-    HIP_TRY(c, hipMemsetAsync(t.ticket, 0, 4, s));
-    HIP_TRY(c, hipMemsetAsync(t.pool_next, 0, 8, s));
-    t.seq = 0;
-    f.nst = nst;
-    f.ntiles = nt;
+    if (!(t.ext0 && f.nst == nst && f.ntiles == nt)) {
+        dfree(t.ext0); dfree(t.meta);
+        f.nst = f.ntiles = 0;
+        f.consts = rtr::StoreConsts{};
+        c->list_valid = false;
+        const size_t meta_bytes = rtr::ts_meta_words(nst, nt) * sizeof(uint32_t);
+        HIP_TRY(c, hipMalloc((void **)&t.ext0, (size_t)nst * rtr::kS0 * sizeof(uint64_t)));
+        HIP_TRY(c, hipMalloc((void **)&t.meta, meta_bytes));
+        HIP_TRY(c, hipMemsetAsync(t.meta, 0, meta_bytes, s));  // stream lengths 0, directory stamps 0 (never current)
+        t.seq = 0;
+        t.nst = f.nst = nst;
+        t.ntiles = f.ntiles = nt;
+    }
+    // header constants: the buffers T1's last workgroup resets for split tiles / writes the occupancy
+    // bitmap to, the dynamic extent pool, the split parameters (uploaded only when one of them changes)
+    rtr::StoreConsts want{};
+    want.depth = c->depth; want.acc = c->acc; want.occ = c->p2p.open ? c->p2p.occ : nullptr;
+    want.dyn = f.dyn; want.dyn_cap = f.dyn_cap;
+    want.heavy = c->opt_heavy > 0 ? (uint32_t)c->opt_heavy : 0xFFFFFFFFu;
+    want.slice = (uint32_t)c->opt_slice;
+    if (memcmp(&want, &f.consts, sizeof want) != 0) {
+        f.consts = want;
+        HIP_TRY(c, hipMemcpyAsync(rtr::ts_hdr(t) + rtr::kHdrConsts, &f.consts, sizeof f.consts, hipMemcpyHostToDevice, s));
+    }
     return RTR_OK;
 }
 
@@ -242,12 +244,12 @@ int ensure_tiles(rtr_ctx *c, hipStream_t s) {
 // point of round 1's wave lists + sorted copy.
 int ensure_lists(rtr_ctx *c) {
     auto &f = c->F();
-    if (f.store.dyn && f.pool_n == c->n) return RTR_OK;
-    dfree(f.store.dyn);
+    if (f.dyn && f.pool_n == c->n) return RTR_OK;
+    dfree(f.dyn);
     c->list_valid = false;
-    f.store.dyn_cap = 2 * c->n + 64;
+    f.dyn_cap = 2 * c->n + 64;
     f.pool_n = c->n;
-    HIP_TRY(c, hipMalloc((void **)&f.store.dyn, f.store.dyn_cap * sizeof(uint64_t)));
+    HIP_TRY(c, hipMalloc((void **)&f.dyn, f.dyn_cap * sizeof(uint64_t)));
     return RTR_OK;
 }
 
@@ -525,6 +527,26 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
         c->list_valid = false;
         return RTR_OK;
     }
+#ifdef RTR_EXPERIMENT
+    if (!strcmp(key, "xp")) {  // timing experiments: parts of T1 switched off, frames become wrong
+        c->opt_xp = value;
+        return RTR_OK;
+    }
+#endif
+    if (!strcmp(key, "fill_shift")) {  // spacing of the tile stream counters: 4 << value bytes
+        NEED(c, value >= 0 && value <= rtr::kFillShiftMax, "fill_shift must be in 0..6");
+        DevGuard g(c->device);
+        HIP_TRY(c, sync_streams(c));
+        c->opt_fill_shift = value;  // (the counters are all zero between frames: any spacing can follow any other)
+        c->list_valid = false;
+        return RTR_OK;
+    }
+    if (!strcmp(key, "phases")) {  // T1: wave groups that start at different places of the cloud (k_project_bin)
+        NEED(c, value >= 1 && value <= 65535, "phases must be in 1..65535");
+        c->opt_phases = value;
+        c->list_valid = false;
+        return RTR_OK;
+    }
     if (!strcmp(key, "split_slice")) {
         NEED(c, value >= 1, "split_slice must be >= 1");
         c->opt_slice = value;
@@ -786,17 +808,16 @@ static int bin_points(rtr_ctx *c, const float P[16], bool overlapped, bool clear
     if (int rc = ensure_lists(c)) return rc;
     if (int rc = ensure_tiles(c, s1)) return rc;
     auto &t = c->F().store;
+    t.fill_shift = c->opt_fill_shift;
     t.seq = (t.seq + 1u) & 0xFFFFFFu;
     if (t.seq == 0u) {  // the 24-bit stamp wrapped: forget every directory entry once
-        HIP_TRY(c, hipMemsetAsync(t.dir, 0, (size_t)c->F().nst * rtr::kDirK * sizeof(unsigned long long), s1));
+        HIP_TRY(c, hipMemsetAsync(rtr::ts_dir(t), 0, (size_t)c->F().nst * rtr::kDirK * sizeof(unsigned long long), s1));
         t.seq = 1u;
     }
-    t.heavy = c->opt_heavy > 0 ? (uint32_t)c->opt_heavy : 0xFFFFFFFFu;
-    t.slice = (uint32_t)c->opt_slice;
     {
         Timed tm(c, RTR_K_MIN_DEPTH, s1);
         rtr::launch_project_bin(s1, cloud_of(c), make_proj(P), c->W, c->H, t, c->opt_cull ? c->bounds : nullptr,
-                                clear_split ? 1 : 0, c->depth, c->acc, c->p2p.open ? c->p2p.occ : nullptr);
+                                clear_split ? 1 : 0, c->opt_phases, c->opt_xp);
         c->p2p.occ_from_scan = c->p2p.open;
     }
     if (overlapped) {
@@ -1089,7 +1110,7 @@ int rtr_p2p_min_depth(rtr_ctx *c) {
     // which screen tiles this rank's frame touches at all (only known when it came from the bins)
     const bool binned = use_tiles(c) && c->list_valid;
     if (!(binned && q.occ_from_scan))  // otherwise the scan kernel of the tile sort has already written it
-        rtr::launch_p2p_occupancy(c->stream, binned ? c->F().store.tile_cnt : nullptr, c->W, c->H, q.occ);
+        rtr::launch_p2p_occupancy(c->stream, binned ? rtr::ts_tile_cnt(c->F().store) : nullptr, c->W, c->H, q.occ);
     q.occ_current = binned;
     q.acc_from_bins = false;
     p2p_barrier(c);  // every rank's local depth (and occupancy) is complete
@@ -1193,9 +1214,9 @@ int rtr_download_buffer(rtr_ctx *c, int which, void *host, size_t bytes) {
 int rtr_frame_stats(rtr_ctx *c, uint32_t out[8]) {
     if (!c) return RTR_ERR_INVALID;
     NEED(c, out != nullptr, "out is NULL");
-    NEED(c, c->F().store.hdr != nullptr, "no binned frame yet");
+    NEED(c, c->F().store.meta != nullptr, "no binned frame yet");
     DevGuard g(c->device);
-    HIP_TRY(c, hipMemcpyAsync(out, c->F().store.hdr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out, rtr::ts_hdr(c->F().store), 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, sync_streams(c));
     return RTR_OK;
 }

@@ -52,25 +52,58 @@ constexpr int kS0Shift = 12;             // static extent: 4096 entries = 32 KB 
 constexpr uint32_t kS0 = 1u << kS0Shift;
 constexpr int kDirK = 21;                // extents 1..20 reach 2^32 entries per storage tile
 constexpr int kHeavyExtra = 512;         // extra tile-kernel workgroups available for split tiles
-struct TileStore {
-    uint64_t *ext0;                 // [nst * kS0]
-    uint64_t *dyn;                  // [dyn_cap] pool of the dynamic extents
-    unsigned long long *pool_next;  // entries of `dyn` handed out in this frame
-    unsigned long long *dir;        // [nst * kDirK] extent base << 24 | frame stamp (valid iff stamp == seq)
-    uint32_t *fill;                 // [nst] stream length while T1 runs; zero between frames
-    uint32_t *count;                // [nst] stream lengths of the binned frame (T1's last workgroup)
-    uint32_t *tile_cnt;             // [ntiles] entries per processing tile (32x32 or 64x32 pixels)
-    uint32_t *items;                // [ntiles + kHeavyExtra] work list of the tile kernel:
-                                    //   tile | sub << 12 | (nsub - 1) << 22; split tiles first
-    uint32_t *hdr;                  // [16] see kHdr*
-    uint32_t *hctr;                 // [ntiles] arrival counters of split tiles
-    uint32_t *ticket;               // T1 workgroups that have finished
-    uint64_t dyn_cap;
-    uint32_t seq;                   // 24-bit frame stamp, never 0
-    uint32_t heavy, slice;          // split tiles with more entries than `heavy` into slices of >= `slice`
+struct TileStore {   // what travels as kernel argument (the point kernel is short of scalar registers)
+    uint64_t *ext0;  // [nst * kS0]
+    uint32_t *meta;  // every small array of the store in ONE allocation (see the ts_* accessors)
+    uint32_t seq;    // 24-bit frame stamp, never 0
+    int nst, ntiles; // 32x16 storage tiles, processing tiles
+    int fill_shift;  // stream counter of storage tile st = fill[st << fill_shift] (one counter per 2^shift words)
 };
+constexpr int kFillShiftMax = 6;
+struct StoreConsts {  // rarely needed, rarely changing: lives in the store's header (hdr[kHdrConsts ..])
+    uint32_t *depth, *acc, *occ;  // frame buffers / occupancy bitmap T1's last workgroup writes to
+    uint64_t *dyn;                // [dyn_cap] pool of the dynamic extents
+    uint64_t dyn_cap;
+    uint32_t heavy, slice;        // split tiles with more entries than `heavy` into slices of >= `slice`
+};
+// meta, in 32-bit words:
+//   fill[nst << kFillShiftMax]  stream length while T1 runs; zero between frames
+//   count[nst]     stream lengths of the binned frame (written by T1's last workgroup)
+//   tile_cnt[nt]   entries per processing tile (32x32 or 64x32 pixels)
+//   hctr[nt]       arrival counters of split tiles
+//   items[nt + kHeavyExtra + 16]  work list of the tile kernel: tile | slice << 12 | (slices - 1) << 22
+//   hdr[32]        kHdr* below; hdr[kHdrConsts ..] = StoreConsts
+//   ticket[2]      T1 workgroups that have finished
+//   pool_next[2]   (u64) entries of `dyn` handed out in this frame
+//   dir[nst * kDirK * 2]  (u64) extent base << 24 | frame stamp (valid iff stamp == seq)
+__host__ __device__ inline size_t ts_even(size_t x) { return (x + 1) & ~(size_t)1; }
+__host__ __device__ inline size_t ts_off_count(int nst, int nt) { return ts_even((size_t)nst << kFillShiftMax); }
+__host__ __device__ inline size_t ts_off_tile_cnt(int nst, int nt) { return ts_off_count(nst, nt) + ts_even((size_t)nst); }
+__host__ __device__ inline size_t ts_off_hctr(int nst, int nt) { return ts_off_tile_cnt(nst, nt) + ts_even((size_t)nt); }
+__host__ __device__ inline size_t ts_off_items(int nst, int nt) { return ts_off_hctr(nst, nt) + ts_even((size_t)nt); }
+__host__ __device__ inline size_t ts_off_hdr(int nst, int nt) { return ts_off_items(nst, nt) + ts_even((size_t)nt + kHeavyExtra + 16); }
+__host__ __device__ inline size_t ts_off_ticket(int nst, int nt) { return ts_off_hdr(nst, nt) + 32; }
+__host__ __device__ inline size_t ts_off_pool(int nst, int nt) { return ts_off_ticket(nst, nt) + 2; }
+__host__ __device__ inline size_t ts_off_dir(int nst, int nt) { return ts_off_pool(nst, nt) + 2; }
+__host__ __device__ inline size_t ts_meta_words(int nst, int nt) { return ts_off_dir(nst, nt) + (size_t)nst * kDirK * 2; }
+__host__ __device__ inline uint32_t *ts_fill(const TileStore &S) { return S.meta; }
+__host__ __device__ inline uint32_t *ts_count(const TileStore &S) { return S.meta + ts_off_count(S.nst, S.ntiles); }
+__host__ __device__ inline uint32_t *ts_tile_cnt(const TileStore &S) { return S.meta + ts_off_tile_cnt(S.nst, S.ntiles); }
+__host__ __device__ inline uint32_t *ts_hctr(const TileStore &S) { return S.meta + ts_off_hctr(S.nst, S.ntiles); }
+__host__ __device__ inline uint32_t *ts_items(const TileStore &S) { return S.meta + ts_off_items(S.nst, S.ntiles); }
+__host__ __device__ inline uint32_t *ts_hdr(const TileStore &S) { return S.meta + ts_off_hdr(S.nst, S.ntiles); }
+__host__ __device__ inline uint32_t *ts_ticket(const TileStore &S) { return S.meta + ts_off_ticket(S.nst, S.ntiles); }
+__host__ __device__ inline unsigned long long *ts_pool(const TileStore &S) {
+    return reinterpret_cast<unsigned long long *>(S.meta + ts_off_pool(S.nst, S.ntiles));
+}
+__host__ __device__ inline unsigned long long *ts_dir(const TileStore &S) {
+    return reinterpret_cast<unsigned long long *>(S.meta + ts_off_dir(S.nst, S.ntiles));
+}
 enum { kHdrItems = 0, kHdrSplitItems = 1, kHdrEntries = 2, kHdrHeaviest = 3, kHdrSlice = 4, kHdrError = 5,
-       kHdrSplitTiles = 6 };
+       kHdrSplitTiles = 6, kHdrConsts = 8 };
+__host__ __device__ inline const StoreConsts *ts_consts(const TileStore &S) {
+    return reinterpret_cast<const StoreConsts *>(ts_hdr(S) + kHdrConsts);
+}
 
 void launch_clear(hipStream_t s, uint32_t *depth, uint32_t *acc, size_t npix);
 // mode 0: the reference's structure (two full streams, global atomics)
@@ -84,11 +117,11 @@ int tile_count(int W, int H);          // processing tiles (32x32, or 64x32 abov
 int storage_tile_count(int W, int H);  // 32x16 storage tiles
 // T1: stream the cloud once, append every in-frustum point to its storage tile's stream; the last
 // workgroup to finish turns the stream lengths into the tile kernel's work list (and, with
-// `clear_split`, resets depth / accumulators of the tiles that will be split; `occ`: 128-word tile
-// occupancy bitmap for the peer-to-peer exchange, may be NULL).
+// `clear_split`, resets depth / accumulators of the tiles that will be split; the frame buffers and
+// the occupancy bitmap of the peer-to-peer exchange are named by StoreConsts in the store's header).
 // bounds != NULL enables per-chunk frustum culling (see k_project_bin)
 void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const TileStore &S,
-                        const float *bounds, int clear_split, uint32_t *depth, uint32_t *acc, uint32_t *occ);
+                        const float *bounds, int clear_split, int phases, int xp = 0);
 void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds);  // 6 floats per 256 points
 int reorder_morton(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, uint64_t n);  // rtr_reorder.hip
 // T4: per-tile LDS z-buffer over the tile store.  mode 0 = whole frame (min + accumulate + resolve

@@ -346,8 +346,15 @@ void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, in
 constexpr int kTileH = 32;
 constexpr int kTileThreads = 512;
 constexpr int kTileBatch = 8;    // entries in flight per thread in k_tile
-constexpr int kMaxGroups = 3;    // tile groups of a quad that get a wave-level claim; the rest claim per lane
+constexpr int kMaxGroups = RTR_MAX_GROUPS;    // tile groups of a quad that get a wave-level claim; the rest claim per lane
 constexpr int kMaxSegs = 4 * kDirK;
+// Timing experiments (tools/kbench.py): `make experiment` builds librtr_hip_xp.so with RTR_EXPERIMENT,
+// where option "xp" switches parts of T1 off (frames become wrong).  The shipped library has none of it.
+#ifdef RTR_EXPERIMENT
+#define RTR_XP(bit) ((xp & (bit)) != 0)
+#else
+#define RTR_XP(bit) false
+#endif
 
 struct TileGeom {
     int tw_shift;  // log2(processing tile width): 5 (32x32) or 6 (64x32)
@@ -381,7 +388,7 @@ __device__ __forceinline__ unsigned long long make_entry(uint32_t depth_bits, ui
     return ((unsigned long long)depth_bits << 33) | ((unsigned long long)pix9 << 24) | (unsigned long long)(colour & 0xFFFFFFu);
 }
 
-__device__ __forceinline__ void store_error(const TileStore &S, uint32_t code) { atomicOr(S.hdr + kHdrError, code); }
+__device__ __forceinline__ void store_error(const TileStore &S, uint32_t code) { atomicOr(ts_hdr(S) + kHdrError, code); }
 
 // Stream position v >= kS0 of storage tile st lies in extent k, which holds [kS0 << (k-1), kS0 << k).
 // The lane that claimed an extent's FIRST position allocates it (one returning add on the pool
@@ -394,9 +401,9 @@ __device__ __forceinline__ unsigned long long extent_alloc(const TileStore &S, u
     const int k = 32 - __clz((int)(v >> kS0Shift));  // 1..20
     const uint32_t start = kS0 << (k - 1);           // first position = size of extent k
     if (v != start) return 0ull;
-    const unsigned long long base = atomicAdd(S.pool_next, (unsigned long long)start);
+    const unsigned long long base = atomicAdd(ts_pool(S), (unsigned long long)start);
     const unsigned long long e = (base << 24) | (unsigned long long)S.seq;
-    __hip_atomic_store(S.dir + (size_t)st * kDirK + k, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ts_dir(S) + (size_t)st * kDirK + k, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return e;
 }
 __device__ __forceinline__ uint64_t *extent_slot(const TileStore &S, uint32_t st, uint32_t v, unsigned long long own) {
@@ -404,7 +411,7 @@ __device__ __forceinline__ uint64_t *extent_slot(const TileStore &S, uint32_t st
     const uint32_t start = kS0 << (k - 1);
     unsigned long long e = own;
     if (e == 0ull) {
-        const unsigned long long *d = S.dir + (size_t)st * kDirK + k;
+        const unsigned long long *d = ts_dir(S) + (size_t)st * kDirK + k;
         int polls = 0;
         for (;;) {
             e = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -417,11 +424,12 @@ __device__ __forceinline__ uint64_t *extent_slot(const TileStore &S, uint32_t st
         }
     }
     const unsigned long long base = e >> 24;
-    if (base + start > S.dyn_cap) {  // cannot happen: the extents of a frame sum to < 2 x its entries
+    const StoreConsts *sc = ts_consts(S);
+    if (base + start > sc->dyn_cap) {  // cannot happen: the extents of a frame sum to < 2 x its entries
         store_error(S, 2u);
         return nullptr;
     }
-    return S.dyn + base + (v - start);
+    return sc->dyn + base + (v - start);
 }
 
 // inclusive scan over a 256-thread workgroup; returns the inclusive prefix, `total` = sum of all
@@ -472,8 +480,13 @@ __device__ __forceinline__ int stream_tile(const TileGeom &g, int tx, int ty, in
 //   count[] <- fill[], fill[] <- 0, entries per processing tile, the tile kernel's work list (split
 //   tiles first, then tiles with more than twice the mean entry count, then the rest), frame
 //   statistics, the occupancy bitmap of the peer-to-peer exchange, and the pool / ticket reset.
-__device__ void bin_epilogue(const TileStore &S, const TileGeom &g, int W, int H, int clear_split,
-                             uint32_t *__restrict__ depth, uint32_t *__restrict__ acc, uint32_t *__restrict__ occ) {
+__device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split) {
+    const TileGeom g = tile_geom(W, H);
+    uint32_t *const fill = ts_fill(S), *const count = ts_count(S), *const tile_cnt = ts_tile_cnt(S);
+    uint32_t *const items = ts_items(S), *const hdr = ts_hdr(S), *const hctr = ts_hctr(S);
+    const StoreConsts sc = *ts_consts(S);
+    uint32_t *const depth = sc.depth, *const acc = sc.acc, *const occ = sc.occ;
+    const uint32_t heavy = sc.heavy;
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_occ[128];
     __shared__ uint32_t s_split[64];  // tiles to reset (more are reset by a second sweep)
@@ -481,30 +494,46 @@ __device__ void bin_epilogue(const TileStore &S, const TileGeom &g, int W, int H
     const int t = threadIdx.x;
     if (t < 128) s_occ[t] = 0;
     if (t == 0) s_nsplit = 0;
+    // This runs alone on the chip at the end of T1: every load below is issued before the first one is
+    // waited for (the loops are fully unrolled; thread t owns tiles t, t + 256, ...: coalesced), so the
+    // epilogue costs a few memory round trips, not one per tile.
     constexpr int PER = 16;  // 256 threads x 16 = 4096 tiles
+    const int wide = g.tw_shift - 5;  // 0: two streams per tile, 1: four
+    uint32_t cnt[PER];
     uint32_t sum = 0, mx = 0, heavy_sum = 0, heavy_n = 0;
-    const int per_tile = 2 << (g.tw_shift - 5);
-#pragma unroll 1
-    for (int k = 0; k < PER; ++k) {
-        const int tile = t * PER + k;
-        uint32_t c = 0;
-        if (tile < g.ntiles) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {  // two batches of 8 tiles: 32 loads in flight, 32 registers
+        uint32_t f[PER / 2][4];
+        int stv[PER / 2][4];
+#pragma unroll
+        for (int k = 0; k < PER / 2; ++k) {
+            const int tile = (half * (PER / 2) + k) * kBlock + t;
             const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
-            for (int s = 0; s < per_tile; ++s) {
-                const int st = stream_tile(g, tx, ty, s);
-                if (st < 0) continue;
-                const uint32_t f = __hip_atomic_load(S.fill + st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                S.count[st] = f;
-                S.fill[st] = 0;
-                c += f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                stv[k][s] = (tile < g.ntiles && s < (2 << wide)) ? stream_tile(g, tx, ty, s) : -1;
+                f[k][s] = stv[k][s] >= 0 ? __hip_atomic_load(fill + ((size_t)stv[k][s] << S.fill_shift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             }
-            S.tile_cnt[tile] = c;  // re-read below by this same thread
         }
-        sum += c;
-        mx = c > mx ? c : mx;
-        if (c > S.heavy) {
-            heavy_sum += c;  // (a frame has < 2^32 entries)
-            heavy_n += 1;
+#pragma unroll
+        for (int k = 0; k < PER / 2; ++k) {
+            const int tile = (half * (PER / 2) + k) * kBlock + t;
+            uint32_t c = 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (stv[k][s] >= 0) {
+                    count[stv[k][s]] = f[k][s];
+                    fill[(size_t)stv[k][s] << S.fill_shift] = 0;
+                    c += f[k][s];
+                }
+            if (tile < g.ntiles) tile_cnt[tile] = c;
+            cnt[half * (PER / 2) + k] = c;
+            sum += c;
+            mx = c > mx ? c : mx;
+            if (c > heavy) {
+                heavy_sum += c;  // (a frame has < 2^32 entries)
+                heavy_n += 1;
+            }
         }
     }
     uint32_t total = 0, heavy_total = 0, n_heavy = 0;
@@ -514,7 +543,7 @@ __device__ void bin_epilogue(const TileStore &S, const TileGeom &g, int W, int H
     mx = block_max256(mx, s_w);
     // slice size: sum of ceil(cnt / slice) over the split tiles <= heavy_total / slice + n_heavy, and the
     // list has room for ntiles + kHeavyExtra items, of which the unsplit tiles take ntiles - n_heavy
-    uint32_t slice = S.slice < 1u ? 1u : S.slice;
+    uint32_t slice = sc.slice < 1u ? 1u : sc.slice;
     {
         const uint32_t need = (uint32_t)(((unsigned long long)heavy_total + kHeavyExtra - 1) / kHeavyExtra);
         slice = need > slice ? need : slice;
@@ -523,67 +552,63 @@ __device__ void bin_epilogue(const TileStore &S, const TileGeom &g, int W, int H
     }
     // split tiles: items [0, n_split_items), one per slice
     uint32_t my_sub = 0;
-#pragma unroll 1
-    for (int k = 0; k < PER; ++k) {
-        const int tile = t * PER + k;
-        const uint32_t c = tile < g.ntiles ? S.tile_cnt[tile] : 0u;
-        if (c > S.heavy) my_sub += (c + slice - 1) / slice;
-    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (cnt[k] > heavy) my_sub += (cnt[k] + slice - 1) / slice;
     uint32_t n_split_items = 0;
     uint32_t pos = block_scan256(my_sub, s_w, n_split_items) - my_sub;
-#pragma unroll 1
-    for (int k = 0; k < PER; ++k) {
-        const int tile = t * PER + k;
-        const uint32_t c = tile < g.ntiles ? S.tile_cnt[tile] : 0u;
-        if (c > S.heavy) {
-            const uint32_t nsub = (c + slice - 1) / slice;
-            for (uint32_t j = 0; j < nsub; ++j) S.items[pos + j] = (uint32_t)tile | (j << 12) | ((nsub - 1u) << 22);
-            pos += nsub;
-            S.hctr[tile] = 0;
-            const uint32_t q = atomicAdd(&s_nsplit, 1u);
-            if (q < 64u) s_split[q] = (uint32_t)tile;
+    if (n_heavy) {  // workgroup-uniform
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int tile = k * kBlock + t;
+            if (cnt[k] > heavy) {
+                const uint32_t nsub = (cnt[k] + slice - 1) / slice;
+                for (uint32_t j = 0; j < nsub; ++j) items[pos + j] = (uint32_t)tile | (j << 12) | ((nsub - 1u) << 22);
+                pos += nsub;
+                hctr[tile] = 0;
+                const uint32_t q = atomicAdd(&s_nsplit, 1u);
+                if (q < 64u) s_split[q] = (uint32_t)tile;
+            }
         }
     }
     // unsplit tiles: those with more than twice the mean entry count first, so the few heavy tiles
     // that bound T4 start at once instead of trailing the launch
     const uint32_t thr = 2u * (total / (uint32_t)g.ntiles) + 1u;
     uint32_t big = 0, light = 0;
-#pragma unroll 1
+#pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int tile = t * PER + k;
-        const uint32_t c = tile < g.ntiles ? S.tile_cnt[tile] : 0u;
-        if (tile < g.ntiles && c <= S.heavy) {
+        const int tile = k * kBlock + t;
+        if (tile < g.ntiles && cnt[k] <= heavy) {
             light += 1;
-            big += c > thr ? 1u : 0u;
+            big += cnt[k] > thr ? 1u : 0u;
         }
     }
     uint32_t n_big = 0, n_light = 0;
     uint32_t big_before = block_scan256(big, s_w, n_big) - big;
     uint32_t light_before = block_scan256(light, s_w, n_light) - light;
-#pragma unroll 1
+#pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int tile = t * PER + k;
-        const uint32_t c = tile < g.ntiles ? S.tile_cnt[tile] : 0u;
-        if (tile < g.ntiles && c <= S.heavy) {
-            const bool b = c > thr;
+        const int tile = k * kBlock + t;
+        if (tile < g.ntiles && cnt[k] <= heavy) {
+            const bool b = cnt[k] > thr;
             const uint32_t p = n_split_items + (b ? big_before : n_big + (light_before - big_before));
-            S.items[p] = (uint32_t)tile;
+            items[p] = (uint32_t)tile;
             big_before += b ? 1u : 0u;
             light_before += 1u;
         }
-        if (c) atomicOr(&s_occ[tile >> 5], 1u << (tile & 31));
+        if (tile < g.ntiles && cnt[k]) atomicOr(&s_occ[tile >> 5], 1u << (tile & 31));
     }
     __syncthreads();
     if (occ && t < 128) occ[t] = s_occ[t];
     if (t == 0) {
-        S.hdr[kHdrItems] = n_split_items + n_light;
-        S.hdr[kHdrSplitItems] = n_split_items;
-        S.hdr[kHdrEntries] = total;
-        S.hdr[kHdrHeaviest] = mx;
-        S.hdr[kHdrSlice] = slice;
-        S.hdr[kHdrSplitTiles] = n_heavy;
-        *S.pool_next = 0ull;
-        *S.ticket = 0u;
+        hdr[kHdrItems] = n_split_items + n_light;
+        hdr[kHdrSplitItems] = n_split_items;
+        hdr[kHdrEntries] = total;
+        hdr[kHdrHeaviest] = mx;
+        hdr[kHdrSlice] = slice;
+        hdr[kHdrSplitTiles] = n_heavy;
+        *ts_pool(S) = 0ull;
+        *ts_ticket(S) = 0u;
     }
     // Whole frames (and sharded frames whose tile launches are the only writers) never clear the frame
     // buffers: an unsplit tile is written by its one workgroup.  The slices of a split tile meet in
@@ -606,7 +631,7 @@ __device__ void bin_epilogue(const TileStore &S, const TileGeom &g, int W, int H
             for (uint32_t q = 0; q < listed; ++q) reset_tile((int)s_split[q]);
         } else {
             for (int tile = 0; tile < g.ntiles; ++tile)
-                if (S.tile_cnt[tile] > S.heavy) reset_tile(tile);  // written by this workgroup above (barrier passed)
+                if (tile_cnt[tile] > heavy) reset_tile(tile);  // written by this workgroup above (barrier passed)
         }
     }
 }
@@ -639,40 +664,64 @@ __device__ void bin_epilogue(const TileStore &S, const TileGeom &g, int W, int H
 // < 3e-7 x that magnitude, so no point the exact arithmetic would keep is ever skipped).
 // Only spatially coherent point orders have tight chunk boxes (rtr_reorder_points).
 template <bool CULL>
-__global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
+__global__ __launch_bounds__(kBlock, 4) void k_project_bin(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
                                                         const float4 *__restrict__ z4,
-                                                        const uint4 *__restrict__ rgba4, uint64_t n4, Proj P, int W,
-                                                        int H, TileGeom g, TileStore S,
-                                                        const float *__restrict__ bounds, int clear_split,
-                                                        uint32_t *__restrict__ depth, uint32_t *__restrict__ acc,
-                                                        uint32_t *__restrict__ occ) {
+                                                        const uint4 *__restrict__ rgba4, uint32_t n4, Proj P, int W,
+                                                        int H, TileStore S, const float *__restrict__ bounds,
+                                                        int clear_split, uint32_t cblock, int xp) {
+    (void)xp;
     const float fW = (float)W, fH = (float)H;
     const float hiW = f_add(fW, 0.25f), hiH = f_add(fH, 0.25f);
-    const uint64_t gtid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const int lane = threadIdx.x & 63;
-
+    const uint32_t stx = (uint32_t)(W + 31) >> 5;  // storage tiles per row (tile_geom)
+    uint32_t *const fill = ts_fill(S);
+    // (a context holds < 2^32 points: quad and chunk indices are 32-bit, which keeps scalar registers free)
+    // Chunk order: a chunk is 256 consecutive points (one quad per lane); round r of the grid stride
+    // is the window of NW consecutive chunks r NW .. r NW + NW - 1, chunk r NW + w going to wave w.
+    // A spatially ordered cloud makes a window ~a million neighbouring points: either none of them is
+    // in the frustum or nearly all are, and then EVERY resident wave waits for its claims at the
+    // same time -- nobody issues loads, HBM drains (T1 208 -> 300 us), and the claims queue up on a
+    // handful of stream counters.  So the waves are cut into `phases` groups of consecutive
+    // workgroups, and group g starts its rounds at g R / phases (wrapping around): at any moment the
+    // groups sit in different windows, about one of them claiming while the others stream, and the
+    // four workgroups resident on a CU (b, b + 256, ...) belong to four different groups.  Inside a
+    // group neighbouring waves still read neighbouring kilobytes (DRAM row locality: dealing runs of
+    // 16 chunks to each wave instead cost +50 us), and every wave still samples the whole cloud.
+    const uint32_t nchunks = (n4 + 63u) / 64u, NW = gridDim.x * (kBlock / 64), wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t R = (nchunks + NW - 1u) / NW;
+    const uint32_t G = cblock < 1u ? 1u : (cblock > gridDim.x ? gridDim.x : cblock);
+    const uint32_t phase = (uint32_t)((uint64_t)((blockIdx.x * G) / gridDim.x) * R / G);
+    auto chunk_of = [&](uint32_t q) -> uint32_t {  // q-th chunk of this wave, q < R (>= nchunks: none)
+        uint32_t r = q + phase;
+        r = r >= R ? r - R : r;
+        const uint64_t c = (uint64_t)r * NW + wave;
+        return (q < R && c < nchunks) ? (uint32_t)c : nchunks;
+    };
     // one quad (four points per lane) of the wave; every exit is wave-uniform
-    auto do_quad = [&](uint64_t i) {
-        float4 X = ld_stream(x4 + i), Y = ld_stream(y4 + i), Z = ld_stream(z4 + i);
+    // the three matrix rows for the four points of a lane (render.cu:33-40); X, Y, Z are dead afterwards
+    struct Rows { float rx[4], ry[4], rz[4]; };
+    auto project_rows = [&](const float4 &X, const float4 &Y, const float4 &Z, Rows &r) {
         const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
-        float rz[4];
-        bool front = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            rz[k] = f_add(fmaf(P.m[10], zs[k], fmaf(P.m[9], ys[k], f_mul(P.m[8], xs[k]))), P.m[11]);
-            front = front || (rz[k] > 0.0f);  // render.cu:63 (NaN fails)
+            r.rz[k] = f_add(fmaf(P.m[10], zs[k], fmaf(P.m[9], ys[k], f_mul(P.m[8], xs[k]))), P.m[11]);
+            r.rx[k] = f_add(fmaf(P.m[2], zs[k], fmaf(P.m[1], ys[k], f_mul(P.m[0], xs[k]))), P.m[3]);
+            r.ry[k] = f_add(fmaf(P.m[6], zs[k], fmaf(P.m[5], ys[k], f_mul(P.m[4], xs[k]))), P.m[7]);
         }
+    };
+    auto do_quad = [&](uint32_t i, bool live, const Rows &r) {
+        const float *rx = r.rx, *ry = r.ry, *rz = r.rz;
+        bool front = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) front = front || (rz[k] > 0.0f);  // render.cu:63 (NaN fails)
+        front = front && live;
         if (__ballot(front) == 0ull) return;
-        float rx[4], ry[4];
         bool maybe[4], any = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            rx[k] = f_add(fmaf(P.m[2], zs[k], fmaf(P.m[1], ys[k], f_mul(P.m[0], xs[k]))), P.m[3]);
-            ry[k] = f_add(fmaf(P.m[6], zs[k], fmaf(P.m[5], ys[k], f_mul(P.m[4], xs[k]))), P.m[7]);
             const float z = rz[k], lo = f_mul(-0.75f, z);
             const bool out = (z > 1e-30f) && ((rx[k] < lo) || (rx[k] > f_mul(hiW, z)) || (ry[k] < lo) || (ry[k] > f_mul(hiH, z)));
-            maybe[k] = (z > 0.0f) && !out;
+            maybe[k] = live && (z > 0.0f) && !out;
             any = any || maybe[k];
         }
         if (__ballot(any) == 0ull) return;
@@ -693,24 +742,29 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
             pm[k] = __ballot(in[k]);
             if (in[k]) {
                 const int u = (int)fu, v = (int)fv;
-                st[k] = (uint32_t)((v >> 4) * g.stx + (u >> 5));
+                st[k] = (uint32_t)(v >> 4) * stx + (uint32_t)(u >> 5);
                 pix[k] = (uint32_t)(((v & 15) << 5) | (u & 31));
             }
         }
-        if ((pm[0] | pm[1] | pm[2] | pm[3]) == 0ull) return;
-        // the lane's four colours in one 16-byte load, issued before the claims return
-        uint4 col = make_uint4(0u, 0u, 0u, 0u);
-        if (in[0] || in[1] || in[2] || in[3]) col = rgba4[i];
+        if ((pm[0] | pm[1] | pm[2] | pm[3]) == 0ull || RTR_XP(8)) return;
+        // the lane's four colours in one 16-byte load, in flight together with the claims.  Unconditional
+        // (and the claims below write variables that have no other definition): a value that merges with
+        // another one at the end of a divergent block is waited for right there, which turned one round
+        // trip per quad into five
+        const uint4 col = rgba4[i];
         // group by storage tile; group `it` is claimed by lane `it`
         // (the claiming lane is the group's first lane: lanes past the end of the cloud are inactive here)
         int grp[4] = {-1, -1, -1, -1};
         uint32_t rank[4] = {0, 0, 0, 0};
-        uint32_t claim[kMaxGroups];
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wuninitialized"
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+        uint32_t claim[kMaxGroups];  // only the claiming lane's value is ever read (readlane below)
+#pragma clang diagnostic pop
         int leader[kMaxGroups];
         int ng = 0;
 #pragma unroll
         for (int it = 0; it < kMaxGroups; ++it) {
-            claim[it] = 0;
             leader[it] = 0;
             const int kk = pm[0] ? 0 : (pm[1] ? 1 : (pm[2] ? 2 : (pm[3] ? 3 : -1)));
             if (kk < 0) continue;  // wave-uniform
@@ -730,7 +784,7 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
                 total += (uint32_t)__popcll(m);
                 pm[k] &= ~m;
             }
-            if (lane == first) claim[it] = atomicAdd(S.fill + lead, total);
+            if (lane == first && !RTR_XP(2)) claim[it] = atomicAdd(fill + ((size_t)lead << S.fill_shift), total);
             leader[it] = first;
             ng = it + 1;
         }
@@ -738,7 +792,7 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (in[k] && grp[k] < 0) {
-                rank[k] = atomicAdd(S.fill + st[k], 1u);
+                rank[k] = atomicAdd(fill + ((size_t)st[k] << S.fill_shift), 1u);
                 grp[k] = kMaxGroups;
             }
         uint32_t base[kMaxGroups];
@@ -756,6 +810,7 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
             v[k] = b + rank[k];
             dyn = dyn || (in[k] && v[k] >= kS0);
         }
+        if (RTR_XP(4)) return;
         if (__ballot(dyn) == 0ull) {  // the usual case: every position lies in its tile's static extent
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -775,12 +830,38 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
     };
 
     if (!CULL) {
-        for (uint64_t i = gtid; i < n4; i += stride) do_quad(i);
+        // Software pipeline: the coordinates of the wave's NEXT quad are requested as soon as the current
+        // ones have gone through the matrix rows, i.e. before the long part of an in-frustum quad (claims,
+        // colour load, stores).  A wave waiting for its claims then still has three kilobyte-loads in
+        // flight, which is what keeps HBM busy with only 4 waves per SIMD.  Lanes past the end of the cloud
+        // re-read its last quad and are masked (`live`).
+        float4 X = make_float4(0.f, 0.f, 0.f, 0.f), Y = X, Z = X;
+        uint32_t i = 0;
+        bool have = false, live = false;
+        auto fetch = [&](uint32_t q) {
+            const uint32_t c = q < R ? chunk_of(q) : nchunks;
+            have = c < nchunks;  // wave-uniform
+            if (have) {
+                i = c * 64u + (uint32_t)lane;
+                live = i < n4;
+                const uint32_t ic = live ? i : n4 - 1u;
+                X = ld_stream(x4 + ic);
+                Y = ld_stream(y4 + ic);
+                Z = ld_stream(z4 + ic);
+            }
+        };
+        fetch(0);
+        for (uint32_t q = 0; q < R; ++q) {
+            Rows r;
+            const bool have_c = have, live_c = live;
+            const uint32_t i_c = i;
+            if (have_c) project_rows(X, Y, Z, r);
+            fetch(q + 1);
+            if (have_c) do_quad(i_c, live_c, r);
+        }
     } else {
-        // The wave owns chunks wave, wave + NW, wave + 2 NW, ... (the same grid-stride order as
-        // above).  64 of them are tested at once, one per lane, then only the survivors are
+        // 64 of the wave's chunks are tested at once, one per lane, then only the survivors are
         // streamed: the box test costs 1/64 and its load latency is paid once per 64 chunks.
-        const uint64_t nchunks = (n4 + 63) / 64, NW = stride >> 6, wave = gtid >> 6;
         float pl[5][4], plm[5][3], pld[5];  // half-space coefficients, |coefficients| row sums, |offset| sums
         {
             const float comb[5][3] = {{0.f, 0.f, 1.f}, {1.f, 0.f, 1.f}, {-1.f, 0.f, fW}, {0.f, 1.f, 1.f}, {0.f, -1.f, fH}};
@@ -794,13 +875,13 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
                 pld[q] = fabsf(comb[q][0] * P.m[3]) + fabsf(comb[q][1] * P.m[7]) + fabsf(comb[q][2] * P.m[11]);
             }
         }
-        for (uint64_t g0 = 0;; g0 += 64) {
-            const uint64_t chunk = wave + (g0 + lane) * NW;
+        for (uint32_t g0 = 0; g0 < R; g0 += 64) {
+            const uint32_t chunk = chunk_of(g0 + (uint32_t)lane);
             const bool valid = chunk < nchunks;
-            if (__ballot(valid) == 0ull) break;
+            if (__ballot(valid) == 0ull) continue;
             bool keep = false;
             if (valid) {
-                const float *b = bounds + 6 * chunk;
+                const float *b = bounds + 6 * (size_t)chunk;
                 const float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
                 bool culled = false;
 #pragma unroll
@@ -821,8 +902,13 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
             while (mask) {
                 const int l = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
-                const uint64_t i = (wave + (g0 + l) * NW) * 64 + lane;
-                if (i < n4) do_quad(i);
+                const uint32_t i = chunk_of(g0 + (uint32_t)l) * 64u + (uint32_t)lane;
+                if (i < n4) {
+                    const float4 X = ld_stream(x4 + i), Y = ld_stream(y4 + i), Z = ld_stream(z4 + i);
+                    Rows r;
+                    project_rows(X, Y, Z, r);
+                    do_quad(i, true, r);
+                }
             }
         }
     }
@@ -830,16 +916,14 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float4 *__restrict
     // last ticket sees every stream length final
     __shared__ uint32_t s_last;
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(S.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+    if (threadIdx.x == 0) s_last = atomicAdd(ts_ticket(S), 1u) == gridDim.x - 1u ? 1u : 0u;
     __syncthreads();
-    if (s_last) bin_epilogue(S, g, W, H, clear_split, depth, acc, occ);
+    if (s_last) bin_epilogue(S, W, H, clear_split);
 }
 
 // frames without points: the epilogue alone
-__global__ __launch_bounds__(kBlock) void k_bin_empty(int W, int H, TileGeom g, TileStore S, int clear_split,
-                                                      uint32_t *__restrict__ depth, uint32_t *__restrict__ acc,
-                                                      uint32_t *__restrict__ occ) {
-    bin_epilogue(S, g, W, H, clear_split, depth, acc, occ);
+__global__ __launch_bounds__(kBlock) void k_bin_empty(int W, int H, TileStore S, int clear_split) {
+    bin_epilogue(S, W, H, clear_split);
 }
 
 __device__ __forceinline__ float min2(float a, float b) { return a < b ? a : b; }  // project_cloud.cu:46-49
@@ -950,10 +1034,11 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(TileStore S, TileGeom g, 
     // store the tile's depth / sums instead of folding them into what memory holds
     const bool overwrite = (write_acc & 2) != 0;
     write_acc &= 1;
-    const uint32_t n_items = MODE == 3 ? S.hdr[kHdrSplitItems] : S.hdr[kHdrItems];
+    const uint32_t n_items = ts_hdr(S)[MODE == 3 ? kHdrSplitItems : kHdrItems];
+    const uint32_t *const items = ts_items(S), *const count = ts_count(S);
 
     for (uint32_t item_i = blockIdx.x; item_i < n_items; item_i += gridDim.x) {
-        const uint32_t item = S.items[item_i];
+        const uint32_t item = items[item_i];
         const int tile = (int)(item & 4095u);
         const uint32_t sub = (item >> 12) & 1023u, nsub = (item >> 22) + 1u;
         const bool split = nsub > 1u;
@@ -968,14 +1053,14 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(TileStore S, TileGeom g, 
             const int s = tid / kDirK, k = tid % kDirK;
             const int st = s < (2 << (g.tw_shift - 5)) ? stream_tile(g, tx, ty, s) : -1;
             if (st >= 0) {
-                const unsigned long long cnt = S.count[st];
+                const unsigned long long cnt = count[st];
                 const unsigned long long a = cnt * sub / nsub, b = cnt * (sub + 1u) / nsub;
                 const unsigned long long e_lo = k == 0 ? 0ull : ((unsigned long long)kS0 << (k - 1));
                 const unsigned long long e_hi = (unsigned long long)kS0 << k;
                 const unsigned long long lo = a > e_lo ? a : e_lo, hi = b < e_hi ? b : e_hi;
                 if (hi > lo) {
                     const uint64_t *p = k == 0 ? S.ext0 + ((size_t)st << kS0Shift) + lo
-                                               : S.dyn + (S.dir[(size_t)st * kDirK + k] >> 24) + (lo - e_lo);
+                                               : ts_consts(S)->dyn + (ts_dir(S)[(size_t)st * kDirK + k] >> 24) + (lo - e_lo);
                     const uint32_t q = atomicAdd(&s_nseg, 1u);
                     s_seg_p[q] = (unsigned long long)p;
                     s_seg_n[q] = (uint32_t)(hi - lo);
@@ -1122,7 +1207,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(TileStore S, TileGeom g, 
             if (MODE == 3) {  // the last slice to arrive resolves the tile from the summed accumulators
                 __threadfence();
                 __syncthreads();
-                if (tid == 0) s_flag = atomicAdd(S.hctr + tile, 1u) == nsub - 1u ? 1u : 0u;
+                if (tid == 0) s_flag = atomicAdd(ts_hctr(S) + tile, 1u) == nsub - 1u ? 1u : 0u;
                 __syncthreads();
                 finish = s_flag != 0u;
                 if (finish) {
@@ -1205,21 +1290,20 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(TileStore S, TileGeom g, 
 }
 
 void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const TileStore &S,
-                        const float *bounds, int clear_split, uint32_t *depth, uint32_t *acc, uint32_t *occ) {
-    TileGeom g = tile_geom(W, H);
+                        const float *bounds, int clear_split, int phases, int xp) {
     uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) {
-        hipLaunchKernelGGL(k_bin_empty, dim3(1), dim3(kBlock), 0, s, W, H, g, S, clear_split, depth, acc, occ);
+        hipLaunchKernelGGL(k_bin_empty, dim3(1), dim3(kBlock), 0, s, W, H, S, clear_split);
         return;
     }
     if (bounds)
         hipLaunchKernelGGL(k_project_bin<true>, dim3(point_grid(n4, c.grid)), dim3(kBlock), 0, s, (const float4 *)c.x,
-                           (const float4 *)c.y, (const float4 *)c.z, (const uint4 *)c.rgba, n4, P, W, H, g, S, bounds,
-                           clear_split, depth, acc, occ);
+                           (const float4 *)c.y, (const float4 *)c.z, (const uint4 *)c.rgba, (uint32_t)n4, P, W, H, S, bounds,
+                           clear_split, (uint32_t)phases, xp);
     else
         hipLaunchKernelGGL(k_project_bin<false>, dim3(point_grid(n4, c.grid)), dim3(kBlock), 0, s, (const float4 *)c.x,
-                           (const float4 *)c.y, (const float4 *)c.z, (const uint4 *)c.rgba, n4, P, W, H, g, S, bounds,
-                           clear_split, depth, acc, occ);
+                           (const float4 *)c.y, (const float4 *)c.z, (const uint4 *)c.rgba, (uint32_t)n4, P, W, H, S, bounds,
+                           clear_split, (uint32_t)phases, xp);
 }
 
 // bounding box of every 256-point chunk (the unit one wave of T1 handles per iteration):
