@@ -224,6 +224,12 @@ int ensure_tiles(rtr_ctx *c, hipStream_t s) {
         t.seq = 0;
         t.nst = f.nst = nst;
         t.ntiles = f.ntiles = nt;
+        {   // launch order of the tile kernel: identity until a frame has been rendered
+            std::vector<uint32_t> ident((size_t)nt);
+            for (int i = 0; i < nt; ++i) ident[(size_t)i] = (uint32_t)i;
+            HIP_TRY(c, hipMemcpyAsync(rtr::ts_perm(t), ident.data(), (size_t)nt * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipStreamSynchronize(s));  // `ident` goes out of scope
+        }
     }
     // header constants: the buffers T1's last workgroup resets for split tiles / writes the occupancy
     // bitmap to, the dynamic extent pool, the split parameters (uploaded only when one of them changes)

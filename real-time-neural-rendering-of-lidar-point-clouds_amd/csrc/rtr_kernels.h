@@ -71,7 +71,12 @@ struct StoreConsts {  // rarely needed, rarely changing: lives in the store's he
 //   count[nst]     stream lengths of the binned frame (written by T1's last workgroup)
 //   tile_cnt[nt]   entries per processing tile (32x32 or 64x32 pixels)
 //   hctr[nt]       arrival counters of split tiles
-//   items[nt + kHeavyExtra + 16]  work list of the tile kernel: tile | slice << 12 | (slices - 1) << 22
+//   items[(2 nt + kHeavyExtra + 1) * 8]  work list of the tile kernel, 32-byte records: word 0 = tile |
+//                  slice << 12 | (slices - 1) << 22, words 1..4 = the lengths of the tile's two (four)
+//                  streams.  Records [0, nt): one per tile, at position perm[tile] (kItemSkip when the
+//                  tile is split); records [nt, nt + hdr[kHdrSplitItems]): the slices of split tiles
+//   perm[nt]       tile -> record position: tiles that held more than twice the mean entry count in
+//                  the PREVIOUS frame first (written by the tile kernel's mode-3 launch)
 //   hdr[32]        kHdr* below; hdr[kHdrConsts ..] = StoreConsts
 //   ticket[2]      T1 workgroups that have finished
 //   pool_next[2]   (u64) entries of `dyn` handed out in this frame
@@ -81,11 +86,12 @@ __host__ __device__ inline size_t ts_off_count(int nst, int nt) { return ts_even
 __host__ __device__ inline size_t ts_off_tile_cnt(int nst, int nt) { return ts_off_count(nst, nt) + ts_even((size_t)nst); }
 __host__ __device__ inline size_t ts_off_hctr(int nst, int nt) { return ts_off_tile_cnt(nst, nt) + ts_even((size_t)nt); }
 __host__ __device__ inline size_t ts_off_items(int nst, int nt) { return ts_off_hctr(nst, nt) + ts_even((size_t)nt); }
-__host__ __device__ inline size_t ts_off_hdr(int nst, int nt) { return ts_off_items(nst, nt) + ts_even((size_t)nt + kHeavyExtra + 16); }
+__host__ __device__ inline size_t ts_off_hdr(int nst, int nt) { return ts_off_items(nst, nt) + ((size_t)2 * nt + kHeavyExtra + 1) * 8; }
 __host__ __device__ inline size_t ts_off_ticket(int nst, int nt) { return ts_off_hdr(nst, nt) + 32; }
 __host__ __device__ inline size_t ts_off_pool(int nst, int nt) { return ts_off_ticket(nst, nt) + 2; }
 __host__ __device__ inline size_t ts_off_dir(int nst, int nt) { return ts_off_pool(nst, nt) + 2; }
-__host__ __device__ inline size_t ts_meta_words(int nst, int nt) { return ts_off_dir(nst, nt) + (size_t)nst * kDirK * 2; }
+__host__ __device__ inline size_t ts_off_perm(int nst, int nt) { return ts_off_dir(nst, nt) + (size_t)nst * kDirK * 2; }
+__host__ __device__ inline size_t ts_meta_words(int nst, int nt) { return ts_off_perm(nst, nt) + ts_even((size_t)nt); }
 __host__ __device__ inline uint32_t *ts_fill(const TileStore &S) { return S.meta; }
 __host__ __device__ inline uint32_t *ts_count(const TileStore &S) { return S.meta + ts_off_count(S.nst, S.ntiles); }
 __host__ __device__ inline uint32_t *ts_tile_cnt(const TileStore &S) { return S.meta + ts_off_tile_cnt(S.nst, S.ntiles); }
@@ -96,6 +102,8 @@ __host__ __device__ inline uint32_t *ts_ticket(const TileStore &S) { return S.me
 __host__ __device__ inline unsigned long long *ts_pool(const TileStore &S) {
     return reinterpret_cast<unsigned long long *>(S.meta + ts_off_pool(S.nst, S.ntiles));
 }
+__host__ __device__ inline uint32_t *ts_perm(const TileStore &S) { return S.meta + ts_off_perm(S.nst, S.ntiles); }
+constexpr uint32_t kItemSkip = 0xFFFFFFFEu;
 __host__ __device__ inline unsigned long long *ts_dir(const TileStore &S) {
     return reinterpret_cast<unsigned long long *>(S.meta + ts_off_dir(S.nst, S.ntiles));
 }

@@ -9,6 +9,8 @@
 
 #include <hip/hip_fp16.h>
 
+#include <type_traits>
+
 namespace rtr {
 
 #define RTR_EMPTY 0x7F7FFFFFu
@@ -432,9 +434,9 @@ __device__ __forceinline__ uint64_t *extent_slot(const TileStore &S, uint32_t st
     return sc->dyn + base + (v - start);
 }
 
-// inclusive scan over a 256-thread workgroup; returns the inclusive prefix, `total` = sum of all
-__device__ __forceinline__ uint32_t block_scan256(uint32_t v, uint32_t *s_w /*[4]*/, uint32_t &total) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+// inclusive scan over the workgroup (<= 8 waves); returns the inclusive prefix, `total` = sum of all
+__device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t *s_w /*[8]*/, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t o = __shfl_up(v, off, 64);
@@ -445,15 +447,15 @@ __device__ __forceinline__ uint32_t block_scan256(uint32_t v, uint32_t *s_w /*[4
     __syncthreads();
     uint32_t base = 0;
     total = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < nw; ++k) {
         const uint32_t w = s_w[k];
         base += k < wv ? w : 0u;
         total += w;
     }
     return v + base;
 }
-__device__ __forceinline__ uint32_t block_max256(uint32_t v, uint32_t *s_w) {
+__device__ __forceinline__ uint32_t block_max(uint32_t v, uint32_t *s_w) {
+    const int nw = blockDim.x >> 6;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const uint32_t o = __shfl_xor(v, off, 64);
@@ -463,8 +465,7 @@ __device__ __forceinline__ uint32_t block_max256(uint32_t v, uint32_t *s_w) {
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
     __syncthreads();
     uint32_t m = s_w[0];
-#pragma unroll
-    for (int k = 1; k < 4; ++k) m = s_w[k] > m ? s_w[k] : m;
+    for (int k = 1; k < nw; ++k) m = s_w[k] > m ? s_w[k] : m;
     return m;
 }
 
@@ -476,132 +477,143 @@ __device__ __forceinline__ int stream_tile(const TileGeom &g, int tx, int ty, in
 }
 
 // The bookkeeping of a binned frame, run by the LAST workgroup of T1 (every stream length is final:
-// each wave waited for its own returning adds before its workgroup took a ticket):
-//   count[] <- fill[], fill[] <- 0, entries per processing tile, the tile kernel's work list (split
-//   tiles first, then tiles with more than twice the mean entry count, then the rest), frame
-//   statistics, the occupancy bitmap of the peer-to-peer exchange, and the pool / ticket reset.
+// each wave waited for its own returning adds before its workgroup took a ticket).  It runs alone on
+// the chip, so it is kept to ONE round of loads and no scan in the usual case:
+//   count[] <- fill[], fill[] <- 0, entries per processing tile, one work-list record per tile at the
+//   position perm[tile] (the launch order of the tile kernel: heavy tiles of the previous frame
+//   first), frame statistics, the occupancy bitmap of the peer-to-peer exchange, pool / ticket reset.
+// Only when some tile exceeds the split threshold are its slices laid out (scans) and, if asked for,
+// its pixels reset.
 __device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split) {
     const TileGeom g = tile_geom(W, H);
     uint32_t *const fill = ts_fill(S), *const count = ts_count(S), *const tile_cnt = ts_tile_cnt(S);
-    uint32_t *const items = ts_items(S), *const hdr = ts_hdr(S), *const hctr = ts_hctr(S);
+    uint32_t *const hdr = ts_hdr(S), *const hctr = ts_hctr(S);
+    const uint32_t *const perm = ts_perm(S);
+    uint4 *const records = reinterpret_cast<uint4 *>(ts_items(S));
     const StoreConsts sc = *ts_consts(S);
     uint32_t *const depth = sc.depth, *const acc = sc.acc, *const occ = sc.occ;
     const uint32_t heavy = sc.heavy;
-    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_w[8];
     __shared__ uint32_t s_occ[128];
     __shared__ uint32_t s_split[64];  // tiles to reset (more are reset by a second sweep)
-    __shared__ uint32_t s_nsplit;
+    __shared__ uint32_t s_nsplit, s_total, s_max;
     const int t = threadIdx.x;
     if (t < 128) s_occ[t] = 0;
-    if (t == 0) s_nsplit = 0;
-    // This runs alone on the chip at the end of T1: every load below is issued before the first one is
-    // waited for (the loops are fully unrolled; thread t owns tiles t, t + 256, ...: coalesced), so the
-    // epilogue costs a few memory round trips, not one per tile.
-    constexpr int PER = 16;  // 256 threads x 16 = 4096 tiles
-    const int wide = g.tw_shift - 5;  // 0: two streams per tile, 1: four
-    uint32_t cnt[PER];
-    uint32_t sum = 0, mx = 0, heavy_sum = 0, heavy_n = 0;
+    if (t == 0) s_nsplit = s_total = s_max = 0;
+    __syncthreads();
+    const int wide = g.tw_shift - 5;  // 0: two streams per tile (32 x 32), 1: four (64 x 32)
+    uint32_t sum = 0, mx = 0, heavy_n = 0;
+    auto load_lengths = [&](auto ns_tag, auto batch_tag) {  // thread t owns tiles t, t + 256, ...: coalesced
+        constexpr int NS = decltype(ns_tag)::value, BATCH = decltype(batch_tag)::value;
+#pragma unroll 1
+        for (int k0 = 0; k0 * kBlock < g.ntiles; k0 += BATCH) {
+            uint32_t f[BATCH][NS], pos[BATCH];
+            int stv[BATCH][NS];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {  // two batches of 8 tiles: 32 loads in flight, 32 registers
-        uint32_t f[PER / 2][4];
-        int stv[PER / 2][4];
+            for (int k = 0; k < BATCH; ++k) {  // every load of the batch is issued before the first one is waited for
+                const int tile = (k0 + k) * kBlock + t;
+                const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+                pos[k] = tile < g.ntiles ? perm[tile] : 0u;
 #pragma unroll
-        for (int k = 0; k < PER / 2; ++k) {
-            const int tile = (half * (PER / 2) + k) * kBlock + t;
-            const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                stv[k][s] = (tile < g.ntiles && s < (2 << wide)) ? stream_tile(g, tx, ty, s) : -1;
-                f[k][s] = stv[k][s] >= 0 ? __hip_atomic_load(fill + ((size_t)stv[k][s] << S.fill_shift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < PER / 2; ++k) {
-            const int tile = (half * (PER / 2) + k) * kBlock + t;
-            uint32_t c = 0;
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                if (stv[k][s] >= 0) {
-                    count[stv[k][s]] = f[k][s];
-                    fill[(size_t)stv[k][s] << S.fill_shift] = 0;
-                    c += f[k][s];
+                for (int s = 0; s < NS; ++s) {
+                    stv[k][s] = tile < g.ntiles ? stream_tile(g, tx, ty, s) : -1;
+                    f[k][s] = stv[k][s] >= 0 ? __hip_atomic_load(fill + ((size_t)stv[k][s] << S.fill_shift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 }
-            if (tile < g.ntiles) tile_cnt[tile] = c;
-            cnt[half * (PER / 2) + k] = c;
-            sum += c;
-            mx = c > mx ? c : mx;
-            if (c > heavy) {
-                heavy_sum += c;  // (a frame has < 2^32 entries)
-                heavy_n += 1;
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int tile = (k0 + k) * kBlock + t;
+                uint32_t c = 0;
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    if (stv[k][s] >= 0) {
+                        count[stv[k][s]] = f[k][s];
+                        fill[(size_t)stv[k][s] << S.fill_shift] = 0;
+                        c += f[k][s];
+                    }
+                if (tile < g.ntiles) {
+                    tile_cnt[tile] = c;
+                    records[2 * (size_t)pos[k]] = make_uint4(c > heavy ? kItemSkip : (uint32_t)tile, f[k][0], f[k][1], NS > 2 ? f[k][NS > 2 ? 2 : 0] : 0u);
+                    records[2 * (size_t)pos[k] + 1] = make_uint4(NS > 2 ? f[k][NS > 2 ? 3 : 0] : 0u, 0u, 0u, 0u);
+                    if (c) atomicOr(&s_occ[tile >> 5], 1u << (tile & 31));
+                }
+                sum += c;
+                mx = c > mx ? c : mx;
+                heavy_n += c > heavy ? 1u : 0u;
             }
         }
-    }
-    uint32_t total = 0, heavy_total = 0, n_heavy = 0;
-    block_scan256(sum, s_w, total);
-    block_scan256(heavy_sum, s_w, heavy_total);
-    block_scan256(heavy_n, s_w, n_heavy);
-    mx = block_max256(mx, s_w);
-    // slice size: sum of ceil(cnt / slice) over the split tiles <= heavy_total / slice + n_heavy, and the
-    // list has room for ntiles + kHeavyExtra items, of which the unsplit tiles take ntiles - n_heavy
-    uint32_t slice = sc.slice < 1u ? 1u : sc.slice;
-    {
-        const uint32_t need = (uint32_t)(((unsigned long long)heavy_total + kHeavyExtra - 1) / kHeavyExtra);
-        slice = need > slice ? need : slice;
-        const uint32_t need2 = (mx + 1023u) / 1024u;  // nsub - 1 has 10 bits
-        slice = need2 > slice ? need2 : slice;
-    }
-    // split tiles: items [0, n_split_items), one per slice
-    uint32_t my_sub = 0;
+    };
+    if (wide)
+        load_lengths(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+    else
+        load_lengths(std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{});
+    // statistics (and the split decision) through LDS atomics: one barrier instead of a scan each
 #pragma unroll
-    for (int k = 0; k < PER; ++k)
-        if (cnt[k] > heavy) my_sub += (cnt[k] + slice - 1) / slice;
-    uint32_t n_split_items = 0;
-    uint32_t pos = block_scan256(my_sub, s_w, n_split_items) - my_sub;
-    if (n_heavy) {  // workgroup-uniform
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int tile = k * kBlock + t;
-            if (cnt[k] > heavy) {
-                const uint32_t nsub = (cnt[k] + slice - 1) / slice;
-                for (uint32_t j = 0; j < nsub; ++j) items[pos + j] = (uint32_t)tile | (j << 12) | ((nsub - 1u) << 22);
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off, 64);
+        const uint32_t o = __shfl_xor(mx, off, 64);
+        mx = o > mx ? o : mx;
+    }
+    if ((t & 63) == 0) {
+        atomicAdd(&s_total, sum);
+        atomicMax(&s_max, mx);
+    }
+    const int any_heavy = __syncthreads_or(heavy_n != 0u);
+    const uint32_t total = s_total;
+    mx = s_max;
+    if (occ && t < 128) occ[t] = s_occ[t];
+    uint32_t n_split_items = 0, n_heavy = 0, slice = sc.slice < 1u ? 1u : sc.slice;
+    if (any_heavy) {  // workgroup-uniform, rare: lay out the slices of the tiles above the split threshold
+        uint32_t heavy_sum = 0;
+#pragma unroll 1
+        for (int tile = t; tile < g.ntiles; tile += kBlock) {
+            const uint32_t c = tile_cnt[tile];  // written above by this same thread
+            heavy_sum += c > heavy ? c : 0u;    // (a frame has < 2^32 entries)
+        }
+        uint32_t heavy_total = 0;
+        block_scan(heavy_sum, s_w, heavy_total);
+        block_scan(heavy_n, s_w, n_heavy);
+        // slice size: sum of ceil(cnt / slice) over the split tiles <= heavy_total / slice + n_heavy, and the
+        // split region of the list has room for ntiles + kHeavyExtra records
+        {
+            const uint32_t need = (uint32_t)(((unsigned long long)heavy_total + kHeavyExtra - 1) / kHeavyExtra);
+            slice = need > slice ? need : slice;
+            const uint32_t need2 = (mx + 1023u) / 1024u;  // nsub - 1 has 10 bits
+            slice = need2 > slice ? need2 : slice;
+        }
+        uint32_t my_sub = 0;
+#pragma unroll 1
+        for (int tile = t; tile < g.ntiles; tile += kBlock) {
+            const uint32_t c = tile_cnt[tile];
+            if (c > heavy) my_sub += (c + slice - 1) / slice;
+        }
+        uint32_t pos = block_scan(my_sub, s_w, n_split_items) - my_sub;
+#pragma unroll 1
+        for (int tile = t; tile < g.ntiles; tile += kBlock) {
+            const uint32_t c = tile_cnt[tile];
+            if (c > heavy) {
+                const uint32_t nsub = (c + slice - 1) / slice;
+                const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+                uint32_t f4[4] = {0u, 0u, 0u, 0u};
+                for (int s = 0; s < (2 << wide); ++s) {
+                    const int st = stream_tile(g, tx, ty, s);
+                    if (st >= 0) f4[s] = count[st];  // written above by this same thread
+                }
+                for (uint32_t j = 0; j < nsub; ++j) {
+                    uint4 *rec = records + 2 * (size_t)((uint32_t)g.ntiles + pos + j);
+                    rec[0] = make_uint4((uint32_t)tile | (j << 12) | ((nsub - 1u) << 22), f4[0], f4[1], f4[2]);
+                    rec[1] = make_uint4(f4[3], 0u, 0u, 0u);
+                }
                 pos += nsub;
                 hctr[tile] = 0;
                 const uint32_t q = atomicAdd(&s_nsplit, 1u);
                 if (q < 64u) s_split[q] = (uint32_t)tile;
             }
         }
+        __syncthreads();
     }
-    // unsplit tiles: those with more than twice the mean entry count first, so the few heavy tiles
-    // that bound T4 start at once instead of trailing the launch
-    const uint32_t thr = 2u * (total / (uint32_t)g.ntiles) + 1u;
-    uint32_t big = 0, light = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int tile = k * kBlock + t;
-        if (tile < g.ntiles && cnt[k] <= heavy) {
-            light += 1;
-            big += cnt[k] > thr ? 1u : 0u;
-        }
-    }
-    uint32_t n_big = 0, n_light = 0;
-    uint32_t big_before = block_scan256(big, s_w, n_big) - big;
-    uint32_t light_before = block_scan256(light, s_w, n_light) - light;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int tile = k * kBlock + t;
-        if (tile < g.ntiles && cnt[k] <= heavy) {
-            const bool b = cnt[k] > thr;
-            const uint32_t p = n_split_items + (b ? big_before : n_big + (light_before - big_before));
-            items[p] = (uint32_t)tile;
-            big_before += b ? 1u : 0u;
-            light_before += 1u;
-        }
-        if (tile < g.ntiles && cnt[k]) atomicOr(&s_occ[tile >> 5], 1u << (tile & 31));
-    }
-    __syncthreads();
-    if (occ && t < 128) occ[t] = s_occ[t];
     if (t == 0) {
-        hdr[kHdrItems] = n_split_items + n_light;
+        hdr[kHdrItems] = (uint32_t)g.ntiles - n_heavy + n_split_items;
         hdr[kHdrSplitItems] = n_split_items;
         hdr[kHdrEntries] = total;
         hdr[kHdrHeaviest] = mx;
@@ -634,6 +646,35 @@ __device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split) 
                 if (tile_cnt[tile] > heavy) reset_tile(tile);  // written by this workgroup above (barrier passed)
         }
     }
+}
+
+// The launch order of the NEXT frame's tile kernel, from this frame's entry counts (consecutive frames
+// look alike): tiles with more than twice the mean entry count first, so the few heavy tiles that
+// bound T4 start at once instead of trailing the launch.  One workgroup of the mode-3 tile launch,
+// which has nothing else to do on ordinary frames -- off T1's critical path.
+__device__ void next_frame_order(const TileStore &S) {
+    __shared__ uint32_t s_w[8];
+    const uint32_t *const tile_cnt = ts_tile_cnt(S);
+    uint32_t *const perm = ts_perm(S);
+    const int t = threadIdx.x, nt = S.ntiles, step = blockDim.x;
+    const uint32_t thr = 2u * (ts_hdr(S)[kHdrEntries] / (uint32_t)nt) + 1u;
+    uint32_t big = 0, all = 0;
+    const int per = (nt + step - 1) / step, lo = t * per;  // contiguous tiles per thread: positions stay tile-ordered
+    for (int k = 0; k < per; ++k)
+        if (lo + k < nt) {
+            all += 1;
+            big += tile_cnt[lo + k] > thr ? 1u : 0u;
+        }
+    uint32_t n_big = 0, n_all = 0;
+    uint32_t big_before = block_scan(big, s_w, n_big) - big;
+    uint32_t all_before = block_scan(all, s_w, n_all) - all;
+    for (int k = 0; k < per; ++k)
+        if (lo + k < nt) {
+            const bool b = tile_cnt[lo + k] > thr;
+            perm[lo + k] = b ? big_before : n_big + (all_before - big_before);
+            big_before += b ? 1u : 0u;
+            all_before += 1u;
+        }
 }
 
 // T1 ------------------------------------------------------------------------------
@@ -724,7 +765,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_project_bin(const float4 *__restr
             maybe[k] = live && (z > 0.0f) && !out;
             any = any || maybe[k];
         }
-        if (__ballot(any) == 0ull) return;
+        if (__ballot(any) == 0ull || RTR_XP(64)) return;
         bool in[4];
         uint32_t st[4], pix[4];
         unsigned long long pm[4];
@@ -772,18 +813,24 @@ __global__ __launch_bounds__(kBlock, 4) void k_project_bin(const float4 *__restr
             const uint32_t sk = kk == 0 ? st[0] : (kk == 1 ? st[1] : (kk == 2 ? st[2] : st[3]));
             const int first = __ffsll((long long)pk) - 1;
             const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)sk, first);
-            uint32_t total = 0;
+            // ranks are lane-major: the (up to four) entries of a lane are neighbours in the stream, so a
+            // lane whose four points share the tile writes them as two 16-byte stores
+            uint32_t total = 0, lower = 0;
+            bool gk[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const bool gk = in[k] && grp[k] < 0 && st[k] == lead;
-                const unsigned long long m = __ballot(gk);
-                if (gk) {
-                    grp[k] = it;
-                    rank[k] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                }
+                gk[k] = in[k] && grp[k] < 0 && st[k] == lead;
+                const unsigned long long m = __ballot(gk[k]);
+                lower += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 total += (uint32_t)__popcll(m);
                 pm[k] &= ~m;
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (gk[k]) {
+                    grp[k] = it;
+                    rank[k] = lower++;
+                }
             if (lane == first && !RTR_XP(2)) claim[it] = atomicAdd(fill + ((size_t)lead << S.fill_shift), total);
             leader[it] = first;
             ng = it + 1;
@@ -812,9 +859,24 @@ __global__ __launch_bounds__(kBlock, 4) void k_project_bin(const float4 *__restr
         }
         if (RTR_XP(4)) return;
         if (__ballot(dyn) == 0ull) {  // the usual case: every position lies in its tile's static extent
+            const bool quad = in[0] && in[1] && in[2] && in[3] && grp[0] < kMaxGroups && grp[0] == grp[1] &&
+                              grp[0] == grp[2] && grp[0] == grp[3];  // same group: same tile, ranks r, r+1, r+2, r+3
+            if (quad) {
+                typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+                struct __attribute__((packed, aligned(8))) Pair { ull2 v; };
+                Pair *dst = reinterpret_cast<Pair *>(S.ext0 + ((size_t)st[0] << kS0Shift) + v[0]);
+                ull2 a, b;
+                a.x = make_entry(__float_as_uint(rz[0]), pix[0], cs[0]);
+                a.y = make_entry(__float_as_uint(rz[1]), pix[1], cs[1]);
+                b.x = make_entry(__float_as_uint(rz[2]), pix[2], cs[2]);
+                b.y = make_entry(__float_as_uint(rz[3]), pix[3], cs[3]);
+                dst[0].v = a;
+                dst[1].v = b;
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (in[k]) S.ext0[((size_t)st[k] << kS0Shift) + v[k]] = make_entry(__float_as_uint(rz[k]), pix[k], cs[k]);
+                for (int k = 0; k < 4; ++k)
+                    if (in[k]) S.ext0[((size_t)st[k] << kS0Shift) + v[k]] = make_entry(__float_as_uint(rz[k]), pix[k], cs[k]);
+            }
         } else {
             unsigned long long own[4];
 #pragma unroll
@@ -918,7 +980,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_project_bin(const float4 *__restr
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd(ts_ticket(S), 1u) == gridDim.x - 1u ? 1u : 0u;
     __syncthreads();
-    if (s_last) bin_epilogue(S, W, H, clear_split);
+    if (s_last && !RTR_XP(32)) bin_epilogue(S, W, H, clear_split);
+    if (s_last && RTR_XP(32) && threadIdx.x == 0) *ts_ticket(S) = 0u;  // (only together with xp 8: nothing was claimed)
 }
 
 // frames without points: the epilogue alone
@@ -1015,7 +1078,7 @@ __device__ __forceinline__ void tile_pyramid(const uint32_t *s_depth, uint32_t *
 // (slices - 1) << 22 from T1's epilogue: an unsplit tile (one slice) is owned by one workgroup,
 // the slices of a split tile are merged through the frame buffers.
 template <int MODE>
-__global__ __launch_bounds__(kTileThreads) void k_tile(TileStore S, TileGeom g, int W, int H, float window,
+__global__ __launch_bounds__(kTileThreads, 6) void k_tile(TileStore S, TileGeom g, int W, int H, float window,
                                                         uint32_t *__restrict__ depth, uint32_t *__restrict__ acc,
                                                         uint8_t *__restrict__ img, int write_acc, TilePyr pyr,
                                                         Sliced dsl) {
@@ -1034,17 +1097,31 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(TileStore S, TileGeom g, 
     // store the tile's depth / sums instead of folding them into what memory holds
     const bool overwrite = (write_acc & 2) != 0;
     write_acc &= 1;
-    const uint32_t n_items = ts_hdr(S)[MODE == 3 ? kHdrSplitItems : kHdrItems];
-    const uint32_t *const items = ts_items(S), *const count = ts_count(S);
+    const uint4 *const records = reinterpret_cast<const uint4 *>(ts_items(S));
+    // Records [0, ntiles): one tile each, for workgroups 0 .. ntiles - 1; records [ntiles, ...): the slices of
+    // split tiles, dealt round-robin to the remaining workgroups (mode 3: to all of them) up to kItemEnd.
+    const uint32_t nt = (uint32_t)g.ntiles;
+    if (MODE == 3 && blockIdx.x == gridDim.x - 1) {  // the extra workgroup of the mode-3 launch
+        next_frame_order(S);
+        return;
+    }
+    const bool tile_wg = MODE != 3 && blockIdx.x < nt;
+    const uint32_t split_step = MODE == 3 ? gridDim.x - 1u : gridDim.x - nt;
+    // (a tile workgroup's record always exists; the others first learn how many slice records there are)
+    const uint32_t n_split = tile_wg ? 0u : ts_hdr(S)[kHdrSplitItems];
+    const uint32_t first = tile_wg ? blockIdx.x : nt + (MODE == 3 ? blockIdx.x : blockIdx.x - nt);
 
-    for (uint32_t item_i = blockIdx.x; item_i < n_items; item_i += gridDim.x) {
-        const uint32_t item = items[item_i];
-        const int tile = (int)(item & 4095u);
+    for (uint32_t item_i = first; tile_wg || item_i < nt + n_split; item_i += split_step) {
+        // one 32-byte record per work item: everything the workgroup needs to find its entries
+        const uint4 rec0 = records[2 * (size_t)item_i], rec1 = records[2 * (size_t)item_i + 1];
+        const uint32_t item = rec0.x;
+        if (item == kItemSkip) break;  // a split tile's own slot (workgroup-uniform)
         const uint32_t sub = (item >> 12) & 1023u, nsub = (item >> 22) + 1u;
         const bool split = nsub > 1u;
+        const int tile = (int)(item & 4095u);
         const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
         const int tx0 = tx << g.tw_shift, ty0 = ty * kTileH;
-        if (item_i != blockIdx.x) __syncthreads();  // the previous item's LDS is no longer read
+        __syncthreads();  // the previous item's LDS is no longer read
         if (tid == 0) s_nseg = 0;
         __syncthreads();
         // the contiguous pieces of this item's entries: per stream the static extent and the dynamic ones,
@@ -1052,10 +1129,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(TileStore S, TileGeom g, 
         if (tid < kMaxSegs) {
             const int s = tid / kDirK, k = tid % kDirK;
             const int st = s < (2 << (g.tw_shift - 5)) ? stream_tile(g, tx, ty, s) : -1;
-            if (st >= 0) {
-                const unsigned long long cnt = count[st];
+            const unsigned long long cnt = s == 0 ? rec0.y : (s == 1 ? rec0.z : (s == 2 ? rec0.w : rec1.x));
+            const unsigned long long e_lo = k == 0 ? 0ull : ((unsigned long long)kS0 << (k - 1));
+            if (st >= 0 && cnt > e_lo) {
                 const unsigned long long a = cnt * sub / nsub, b = cnt * (sub + 1u) / nsub;
-                const unsigned long long e_lo = k == 0 ? 0ull : ((unsigned long long)kS0 << (k - 1));
                 const unsigned long long e_hi = (unsigned long long)kS0 << k;
                 const unsigned long long lo = a > e_lo ? a : e_lo, hi = b < e_hi ? b : e_hi;
                 if (hi > lo) {
@@ -1106,54 +1183,72 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(TileStore S, TileGeom g, 
         bool narrow = do_acc && (n_local <= 60000u);
         if (do_acc)
             for (int p = tid; p < (narrow ? 2 : 4) * tpix; p += T) s_acc[p] = 0;
-        if (do_min) {
+        auto min_one = [&](unsigned long long r, uint32_t pb) {  // render.cu:81, behind an early-z read: an LDS read
+            // costs a fraction of an LDS atomic, and only a few entries per pixel lower its minimum
+            const uint32_t d = (uint32_t)(r >> 33), px = (uint32_t)(r >> 24) & 511u;
+            uint32_t *slot = &s_depth[pb + ((px >> 5) << g.tw_shift) + (px & 31u)];
+            if (d < *reinterpret_cast<volatile uint32_t *>(slot)) atomicMin(slot, d);
+        };
+        auto acc_one = [&](unsigned long long r, uint32_t pb, bool packed) {
+            const uint32_t d = (uint32_t)(r >> 33), px = (uint32_t)(r >> 24) & 511u;
+            const uint32_t p = pb + ((px >> 5) << g.tw_shift) + (px & 31u);
+            const float m = __uint_as_float(s_depth[p]);
+            if (!(__uint_as_float(d) > f_add(m, window))) {  // render.cu:106, then :125-128
+                const unsigned long long c0 = r & 0xFFull, c1 = (r >> 8) & 0xFFull, c2 = (r >> 16) & 0xFFull;
+                if (packed) {
+                    atomicAdd(s_acc64 + p, c0 | (c1 << 16) | (c2 << 32) | (1ull << 48));
+                } else {
+                    atomicAdd(s_acc64 + 2 * p + 0, c0 | (c1 << 32));
+                    atomicAdd(s_acc64 + 2 * p + 1, c2 | (1ull << 32));
+                }
+            }
+        };
+        constexpr unsigned long long kPadMin = (unsigned long long)RTR_EMPTY << 33;  // never lowers a minimum
+        constexpr unsigned long long kPadAcc = 0x7F800000ull << 33;                  // +inf fails every window test
+        // Most tiles hold fewer entries than one batch of the workgroup (8 per thread): those are read
+        // ONCE and stay in registers across the barrier between the two reference passes.  The eight
+        // registers of a thread are dealt to the segments statically (2 segments: 4 each, ...), so a
+        // register's segment is workgroup-uniform.
+        const int sh = nseg <= 2u ? 2 : (nseg <= 4u ? 1 : 0);  // log2(registers per segment)
+        bool fits = MODE == 0 && !split && nseg <= (uint32_t)kTileBatch;
+        for (uint32_t q = 0; q < nseg && fits; ++q) fits = s_seg_n[q] <= (T << sh);
+        const bool one_batch = fits;
+        unsigned long long r[kTileBatch];
+        if (one_batch) {
+#pragma unroll
+            for (int k = 0; k < kTileBatch; ++k) {
+                const uint32_t q = (uint32_t)k >> sh, e = tid + ((uint32_t)k & ((1u << sh) - 1u)) * T;
+                r[k] = (q < nseg && e < s_seg_n[q]) ? reinterpret_cast<const unsigned long long *>(s_seg_p[q])[e] : kPadAcc;
+            }
+#pragma unroll
+            for (int k = 0; k < kTileBatch; ++k) min_one(r[k], s_seg_pb[(uint32_t)k >> sh]);  // (+inf lowers no minimum)
+        } else if (do_min) {
             for (uint32_t q = 0; q < nseg; ++q) {
                 const unsigned long long *ent = reinterpret_cast<const unsigned long long *>(s_seg_p[q]);
                 const uint32_t n = s_seg_n[q], pb = s_seg_pb[q];
                 for (uint32_t e = tid; e < n; e += kTileBatch * T) {
-                    unsigned long long r[kTileBatch];
 #pragma unroll
-                    for (int k = 0; k < kTileBatch; ++k) {
-                        const uint32_t ee = e + k * T;
-                        r[k] = (ee < n) ? ent[ee] : ((unsigned long long)RTR_EMPTY << 33);
-                    }
+                    for (int k = 0; k < kTileBatch; ++k) r[k] = (e + k * T < n) ? ent[e + k * T] : kPadMin;
 #pragma unroll
-                    for (int k = 0; k < kTileBatch; ++k) {  // render.cu:81, behind an early-z read: an LDS read
-                        // costs a fraction of an LDS atomic, and only a few entries per pixel lower its minimum
-                        const uint32_t d = (uint32_t)(r[k] >> 33), px = (uint32_t)(r[k] >> 24) & 511u;
-                        uint32_t *slot = &s_depth[pb + ((px >> 5) << g.tw_shift) + (px & 31u)];
-                        if (d < *reinterpret_cast<volatile uint32_t *>(slot)) atomicMin(slot, d);
-                    }
+                    for (int k = 0; k < kTileBatch; ++k) min_one(r[k], pb);
                 }
             }
         }
         __syncthreads();
         auto accumulate = [&](bool packed) {
+            if (one_batch) {
+#pragma unroll
+                for (int k = 0; k < kTileBatch; ++k) acc_one(r[k], s_seg_pb[(uint32_t)k >> sh], packed);
+                return;
+            }
             for (uint32_t q = 0; q < nseg; ++q) {
                 const unsigned long long *ent = reinterpret_cast<const unsigned long long *>(s_seg_p[q]);
                 const uint32_t n = s_seg_n[q], pb = s_seg_pb[q];
-                for (uint32_t e = tid; e < n; e += kTileBatch * T) {
-                    unsigned long long r[kTileBatch];
+                for (uint32_t e = tid; e < n; e += kTileBatch * T) {  // (r is free here: not the one-batch case)
 #pragma unroll
-                    for (int k = 0; k < kTileBatch; ++k) {
-                        const uint32_t ee = e + k * T;
-                        r[k] = (ee < n) ? ent[ee] : (0x7F800000ull << 33);  // +inf fails every window test
-                    }
+                    for (int k = 0; k < kTileBatch; ++k) r[k] = (e + k * T < n) ? ent[e + k * T] : kPadAcc;
 #pragma unroll
-                    for (int k = 0; k < kTileBatch; ++k) {
-                        const uint32_t d = (uint32_t)(r[k] >> 33), px = (uint32_t)(r[k] >> 24) & 511u;
-                        const uint32_t p = pb + ((px >> 5) << g.tw_shift) + (px & 31u);
-                        const float m = __uint_as_float(s_depth[p]);
-                        if (!(__uint_as_float(d) > f_add(m, window))) {  // render.cu:106, then :125-128
-                            const unsigned long long c0 = r[k] & 0xFFull, c1 = (r[k] >> 8) & 0xFFull, c2 = (r[k] >> 16) & 0xFFull;
-                            if (packed) {
-                                atomicAdd(s_acc64 + p, c0 | (c1 << 16) | (c2 << 32) | (1ull << 48));
-                            } else {
-                                atomicAdd(s_acc64 + 2 * p + 0, c0 | (c1 << 32));
-                                atomicAdd(s_acc64 + 2 * p + 1, c2 | (1ull << 32));
-                            }
-                        }
-                    }
+                    for (int k = 0; k < kTileBatch; ++k) acc_one(r[k], pb, packed);
                 }
             }
         };
@@ -1269,8 +1364,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(TileStore S, TileGeom g, 
             if (fast) {
                 const uint32_t *s_rgb32 = reinterpret_cast<const uint32_t *>(s_rgb);
                 for (int q = tid; q < row_dw * kTileH; q += T) {
-                    int r = q / row_dw, dw = q - r * row_dw, y = ty0 + r;
-                    if (y < H) reinterpret_cast<uint32_t *>(img + ((size_t)y * W + tx0) * 3)[dw] = s_rgb32[r * row_dw + dw];
+                    int rr = q / row_dw, dw = q - rr * row_dw, y = ty0 + rr;
+                    if (y < H) reinterpret_cast<uint32_t *>(img + ((size_t)y * W + tx0) * 3)[dw] = s_rgb32[rr * row_dw + dw];
                 }
             } else {
                 for (int q = tid; q < 3 * tpix; q += T) {
@@ -1286,6 +1381,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(TileStore S, TileGeom g, 
             __syncthreads();                      // the sums have been read out of s_acc
             tile_pyramid(s_depth, s_acc, g, tx0, ty0, pyr.L, pyr.n_eff_rows, pyr.part_min, pyr.part_max, tile, tid, T);
         }
+        if (tile_wg) break;
     }
 }
 
@@ -1365,7 +1461,7 @@ void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, floa
         hipLaunchKernelGGL(k_tile<0>, grid, block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 1,
                            pyr ? *pyr : none, nosl);
     else if (mode == 3)  // only the split tiles' slices: all of these workgroups leave at once on ordinary frames
-        hipLaunchKernelGGL(k_tile<3>, dim3(kHeavyExtra), block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 1,
+        hipLaunchKernelGGL(k_tile<3>, dim3(kHeavyExtra + 1), block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 1,
                            pyr ? *pyr : none, nosl);
     else if (mode == 1)
         hipLaunchKernelGGL(k_tile<1>, grid, block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 2, none, nosl);
