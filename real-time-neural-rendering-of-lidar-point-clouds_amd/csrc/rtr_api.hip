@@ -67,7 +67,7 @@ struct rtr_ctx {
     bool force_atomic = false;       // set around a whole frame that takes the atomic form (> 4096 tiles)
     int opt_heavy = 32768;           // tiles with more entries are split over several workgroups in T4 ...
     int opt_slice = 16384;           // ... into slices of at least this many entries
-    int opt_fill_shift = 5;          // stream counters 2^5 words = 128 B apart (see "fill_shift")
+    int opt_fill_shift = 2;          // stream counters 2^2 words = 16 B apart (see "fill_shift")
     int opt_xp = 0;                  // RTR_EXPERIMENT builds only (tools/kbench.py)
     int opt_phases = 1;         // T1: phase groups of the grid stride (option "phases", see k_project_bin)
     int opt_probe = 0;          // rtr_stream_probe variant (experiments)
@@ -1216,6 +1216,16 @@ int rtr_download_buffer(rtr_ctx *c, int which, void *host, size_t bytes) {
 }
 
 // ---- measurement -------------------------------------------------------------------
+
+#ifdef RTR_EXPERIMENT
+extern "C" int rtr_debug_stamps(rtr_ctx *c, unsigned long long out[64]) {  // timing-experiment builds only
+    if (!c || !out || !c->F().store.meta) return RTR_ERR_INVALID;
+    DevGuard g(c->device);
+    HIP_TRY(c, hipMemcpyAsync(out, rtr::ts_dbg(c->F().store), 64 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, sync_streams(c));
+    return RTR_OK;
+}
+#endif
 
 int rtr_frame_stats(rtr_ctx *c, uint32_t out[8]) {
     if (!c) return RTR_ERR_INVALID;

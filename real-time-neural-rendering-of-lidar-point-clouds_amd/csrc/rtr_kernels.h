@@ -68,7 +68,7 @@ struct StoreConsts {  // rarely needed, rarely changing: lives in the store's he
 };
 // meta, in 32-bit words:
 //   fill[nst << kFillShiftMax]  stream length while T1 runs; zero between frames
-//   count[nst]     stream lengths of the binned frame (written by T1's last workgroup)
+//   (nst words, unused)
 //   tile_cnt[nt]   entries per processing tile (32x32 or 64x32 pixels)
 //   hctr[nt]       arrival counters of split tiles
 //   items[(2 nt + kHeavyExtra + 1) * 8]  work list of the tile kernel, 32-byte records: word 0 = tile |
@@ -91,7 +91,8 @@ __host__ __device__ inline size_t ts_off_ticket(int nst, int nt) { return ts_off
 __host__ __device__ inline size_t ts_off_pool(int nst, int nt) { return ts_off_ticket(nst, nt) + 2; }
 __host__ __device__ inline size_t ts_off_dir(int nst, int nt) { return ts_off_pool(nst, nt) + 2; }
 __host__ __device__ inline size_t ts_off_perm(int nst, int nt) { return ts_off_dir(nst, nt) + (size_t)nst * kDirK * 2; }
-__host__ __device__ inline size_t ts_meta_words(int nst, int nt) { return ts_off_perm(nst, nt) + ts_even((size_t)nt); }
+__host__ __device__ inline size_t ts_off_dbg(int nst, int nt) { return ts_off_perm(nst, nt) + ts_even((size_t)nt); }
+__host__ __device__ inline size_t ts_meta_words(int nst, int nt) { return ts_off_dbg(nst, nt) + 128; }  // 64 u64 time stamps (RTR_EXPERIMENT builds)
 __host__ __device__ inline uint32_t *ts_fill(const TileStore &S) { return S.meta; }
 __host__ __device__ inline uint32_t *ts_count(const TileStore &S) { return S.meta + ts_off_count(S.nst, S.ntiles); }
 __host__ __device__ inline uint32_t *ts_tile_cnt(const TileStore &S) { return S.meta + ts_off_tile_cnt(S.nst, S.ntiles); }
@@ -104,6 +105,9 @@ __host__ __device__ inline unsigned long long *ts_pool(const TileStore &S) {
 }
 __host__ __device__ inline uint32_t *ts_perm(const TileStore &S) { return S.meta + ts_off_perm(S.nst, S.ntiles); }
 constexpr uint32_t kItemSkip = 0xFFFFFFFEu;
+__host__ __device__ inline unsigned long long *ts_dbg(const TileStore &S) {
+    return reinterpret_cast<unsigned long long *>(S.meta + ts_off_dbg(S.nst, S.ntiles));
+}
 __host__ __device__ inline unsigned long long *ts_dir(const TileStore &S) {
     return reinterpret_cast<unsigned long long *>(S.meta + ts_off_dir(S.nst, S.ntiles));
 }

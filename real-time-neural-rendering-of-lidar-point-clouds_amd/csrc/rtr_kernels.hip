@@ -346,16 +346,24 @@ void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, in
 //                      minimum into the accumulators, and its last workgroup per tile resolves.
 // Results are identical to the atomic form because min and integer sums commute.
 constexpr int kTileH = 32;
-constexpr int kTileThreads = 512;
-constexpr int kTileBatch = 8;    // entries in flight per thread in k_tile
+#ifndef RTR_TILE_THREADS
+#define RTR_TILE_THREADS 512
+#define RTR_TILE_BATCH 8
+#define RTR_TILE_WAVES 6
+#endif
+constexpr int kTileThreads = RTR_TILE_THREADS;
+constexpr int kTileBatch = RTR_TILE_BATCH;    // entries in flight per thread in k_tile
+constexpr int kPer2 = kTileBatch / 2, kPer4 = kTileBatch / 4;  // registers per stream of a 2- / 4-stream tile
 constexpr int kMaxGroups = RTR_MAX_GROUPS;    // tile groups of a quad that get a wave-level claim; the rest claim per lane
 constexpr int kMaxSegs = 4 * kDirK;
 // Timing experiments (tools/kbench.py): `make experiment` builds librtr_hip_xp.so with RTR_EXPERIMENT,
 // where option "xp" switches parts of T1 off (frames become wrong).  The shipped library has none of it.
 #ifdef RTR_EXPERIMENT
 #define RTR_XP(bit) ((xp & (bit)) != 0)
+#define RTR_STAMP(S, slot) do { if (threadIdx.x == 0) ts_dbg(S)[slot] = wall_clock64(); } while (0)
 #else
 #define RTR_XP(bit) false
+#define RTR_STAMP(S, slot) do { } while (0)
 #endif
 
 struct TileGeom {
@@ -479,20 +487,24 @@ __device__ __forceinline__ int stream_tile(const TileGeom &g, int tx, int ty, in
 // The bookkeeping of a binned frame, run by the LAST workgroup of T1 (every stream length is final:
 // each wave waited for its own returning adds before its workgroup took a ticket).  It runs alone on
 // the chip, so it is kept to ONE round of loads and no scan in the usual case:
-//   count[] <- fill[], fill[] <- 0, entries per processing tile, one work-list record per tile at the
+//   fill[] <- 0, entries per processing tile, one work-list record (with the stream lengths) per tile at the
 //   position perm[tile] (the launch order of the tile kernel: heavy tiles of the previous frame
 //   first), frame statistics, the occupancy bitmap of the peer-to-peer exchange, pool / ticket reset.
 // Only when some tile exceeds the split threshold are its slices laid out (scans) and, if asked for,
 // its pixels reset.
 __device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split) {
     const TileGeom g = tile_geom(W, H);
-    uint32_t *const fill = ts_fill(S), *const count = ts_count(S), *const tile_cnt = ts_tile_cnt(S);
+    uint32_t *const fill = ts_fill(S), *const tile_cnt = ts_tile_cnt(S);
     uint32_t *const hdr = ts_hdr(S), *const hctr = ts_hctr(S);
     const uint32_t *const perm = ts_perm(S);
     uint4 *const records = reinterpret_cast<uint4 *>(ts_items(S));
+    RTR_STAMP(S, 1);
     const StoreConsts sc = *ts_consts(S);
     uint32_t *const depth = sc.depth, *const acc = sc.acc, *const occ = sc.occ;
     const uint32_t heavy = sc.heavy;
+#ifdef RTR_EXPERIMENT
+    if (threadIdx.x == 0 && heavy != 7u) ts_dbg(S)[5] = wall_clock64();  // consts have arrived
+#endif
     __shared__ uint32_t s_w[8];
     __shared__ uint32_t s_occ[128];
     __shared__ uint32_t s_split[64];  // tiles to reset (more are reset by a second sweep)
@@ -513,13 +525,20 @@ __device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split) 
             for (int k = 0; k < BATCH; ++k) {  // every load of the batch is issued before the first one is waited for
                 const int tile = (k0 + k) * kBlock + t;
                 const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
-                pos[k] = tile < g.ntiles ? perm[tile] : 0u;
+                // (unconditional loads from clamped indices: a load whose result merges with a constant at the
+                // end of a branch is waited for right there, which serialised the batch: 10 us instead of 2)
+                pos[k] = perm[tile < g.ntiles ? tile : 0];
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     stv[k][s] = tile < g.ntiles ? stream_tile(g, tx, ty, s) : -1;
-                    f[k][s] = stv[k][s] >= 0 ? __hip_atomic_load(fill + ((size_t)stv[k][s] << S.fill_shift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    const uint32_t got = __hip_atomic_load(fill + ((size_t)(stv[k][s] >= 0 ? stv[k][s] : 0) << S.fill_shift),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    f[k][s] = stv[k][s] >= 0 ? got : 0u;
                 }
             }
+#ifdef RTR_EXPERIMENT
+            if (threadIdx.x == 0 && k0 == 0 && (f[0][0] | pos[0]) != 0xFFFFFFFFu) ts_dbg(S)[6] = wall_clock64();  // first loads back
+#endif
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
                 const int tile = (k0 + k) * kBlock + t;
@@ -527,7 +546,6 @@ __device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split) 
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
                     if (stv[k][s] >= 0) {
-                        count[stv[k][s]] = f[k][s];
                         fill[(size_t)stv[k][s] << S.fill_shift] = 0;
                         c += f[k][s];
                     }
@@ -547,6 +565,7 @@ __device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split) 
         load_lengths(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
     else
         load_lengths(std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{});
+    RTR_STAMP(S, 2);
     // statistics (and the split decision) through LDS atomics: one barrier instead of a scan each
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -559,6 +578,7 @@ __device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split) 
         atomicMax(&s_max, mx);
     }
     const int any_heavy = __syncthreads_or(heavy_n != 0u);
+    RTR_STAMP(S, 3);
     const uint32_t total = s_total;
     mx = s_max;
     if (occ && t < 128) occ[t] = s_occ[t];
@@ -593,16 +613,11 @@ __device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split) 
             const uint32_t c = tile_cnt[tile];
             if (c > heavy) {
                 const uint32_t nsub = (c + slice - 1) / slice;
-                const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
-                uint32_t f4[4] = {0u, 0u, 0u, 0u};
-                for (int s = 0; s < (2 << wide); ++s) {
-                    const int st = stream_tile(g, tx, ty, s);
-                    if (st >= 0) f4[s] = count[st];  // written above by this same thread
-                }
+                const uint4 own0 = records[2 * (size_t)perm[tile]], own1 = records[2 * (size_t)perm[tile] + 1];  // written above by this same thread
                 for (uint32_t j = 0; j < nsub; ++j) {
                     uint4 *rec = records + 2 * (size_t)((uint32_t)g.ntiles + pos + j);
-                    rec[0] = make_uint4((uint32_t)tile | (j << 12) | ((nsub - 1u) << 22), f4[0], f4[1], f4[2]);
-                    rec[1] = make_uint4(f4[3], 0u, 0u, 0u);
+                    rec[0] = make_uint4((uint32_t)tile | (j << 12) | ((nsub - 1u) << 22), own0.y, own0.z, own0.w);
+                    rec[1] = own1;
                 }
                 pos += nsub;
                 hctr[tile] = 0;
@@ -622,6 +637,7 @@ __device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split) 
         *ts_pool(S) = 0ull;
         *ts_ticket(S) = 0u;
     }
+    RTR_STAMP(S, 4);
     // Whole frames (and sharded frames whose tile launches are the only writers) never clear the frame
     // buffers: an unsplit tile is written by its one workgroup.  The slices of a split tile meet in
     // memory (atomicMin / atomicAdd), which therefore has to start from the sentinel / zero.
@@ -977,9 +993,15 @@ __global__ __launch_bounds__(kBlock, 4) void k_project_bin(const float4 *__restr
     // every claim of this workgroup has returned (its value was used); the workgroup that takes the
     // last ticket sees every stream length final
     __shared__ uint32_t s_last;
+#ifdef RTR_EXPERIMENT
+    const unsigned long long t_done = wall_clock64();
+#endif
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd(ts_ticket(S), 1u) == gridDim.x - 1u ? 1u : 0u;
     __syncthreads();
+#ifdef RTR_EXPERIMENT
+    if (s_last && threadIdx.x == 0) ts_dbg(S)[0] = t_done;
+#endif
     if (s_last && !RTR_XP(32)) bin_epilogue(S, W, H, clear_split);
     if (s_last && RTR_XP(32) && threadIdx.x == 0) *ts_ticket(S) = 0u;  // (only together with xp 8: nothing was claimed)
 }
@@ -1078,7 +1100,7 @@ __device__ __forceinline__ void tile_pyramid(const uint32_t *s_depth, uint32_t *
 // (slices - 1) << 22 from T1's epilogue: an unsplit tile (one slice) is owned by one workgroup,
 // the slices of a split tile are merged through the frame buffers.
 template <int MODE>
-__global__ __launch_bounds__(kTileThreads, 6) void k_tile(TileStore S, TileGeom g, int W, int H, float window,
+__global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore S, TileGeom g, int W, int H, float window,
                                                         uint32_t *__restrict__ depth, uint32_t *__restrict__ acc,
                                                         uint8_t *__restrict__ img, int write_acc, TilePyr pyr,
                                                         Sliced dsl) {
@@ -1112,6 +1134,14 @@ __global__ __launch_bounds__(kTileThreads, 6) void k_tile(TileStore S, TileGeom 
     const uint32_t first = tile_wg ? blockIdx.x : nt + (MODE == 3 ? blockIdx.x : blockIdx.x - nt);
 
     for (uint32_t item_i = first; tile_wg || item_i < nt + n_split; item_i += split_step) {
+#ifdef RTR_EXPERIMENT
+        const bool stamp = MODE == 0 && (blockIdx.x == 5 || blockIdx.x == 700 || blockIdx.x == 1900);
+        const int sb = blockIdx.x == 5 ? 8 : (blockIdx.x == 700 ? 24 : 40);
+#define RTR_TSTAMP(k) do { if (stamp && tid == 0) ts_dbg(S)[sb + (k)] = wall_clock64(); } while (0)
+#else
+#define RTR_TSTAMP(k) do { } while (0)
+#endif
+        RTR_TSTAMP(0);
         // one 32-byte record per work item: everything the workgroup needs to find its entries
         const uint4 rec0 = records[2 * (size_t)item_i], rec1 = records[2 * (size_t)item_i + 1];
         const uint32_t item = rec0.x;
@@ -1121,12 +1151,51 @@ __global__ __launch_bounds__(kTileThreads, 6) void k_tile(TileStore S, TileGeom 
         const int tile = (int)(item & 4095u);
         const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
         const int tx0 = tx << g.tw_shift, ty0 = ty * kTileH;
+        // (the segment pointers come out of LDS as integers: say that they are global memory, or the loads go flat)
+        typedef const unsigned long long __attribute__((address_space(1))) *entries_t;
+        constexpr unsigned long long kPadMin = (unsigned long long)RTR_EMPTY << 33;  // never lowers a minimum
+        constexpr unsigned long long kPadAcc = 0x7F800000ull << 33;                  // +inf fails every window test
+        // Most tiles hold fewer entries than one batch of the workgroup (8 per thread) in the static extents
+        // of their two (four) streams: those are requested right here, before the LDS tile is even
+        // initialised, read ONCE and kept in registers across the barrier between the two reference passes.
+        // Register group q of a thread holds CONSECUTIVE entries of stream q.
+        const int ns = 2 << (g.tw_shift - 5);  // streams
+        const bool two = ns == 2;
+        const uint32_t lim = T * (two ? kPer2 : kPer4);  // (<= 2048 < kS0: inside the static extent)
+        static_assert(kTileThreads * kPer2 <= (int)kS0, "one batch must fit the static extent");
+        const bool one_batch = MODE == 0 && !split && rec0.y <= lim && rec0.z <= lim && (ns == 2 || (rec0.w <= lim && rec1.x <= lim));
+        unsigned long long r[kTileBatch];
+        auto load_batch = [&](auto per_tag) {  // (compile-time register -> stream mapping: everything stays in registers)
+            constexpr int PER = decltype(per_tag)::value;
+#pragma unroll
+            for (int q = 0; q < kTileBatch / PER; ++q) {
+                const int st = stream_tile(g, tx, ty, q);
+                const entries_t src = (entries_t)(S.ext0 + ((size_t)(st >= 0 ? st : 0) << kS0Shift));
+                const uint32_t cq = q == 0 ? rec0.y : (q == 1 ? rec0.z : (q == 2 ? rec0.w : rec1.x));
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    // unconditional load (e < 2048 lies inside the static extent whatever the stream's length; a
+                    // load that merges with a constant at the end of a branch is waited for on the spot), masked after
+                    const uint32_t e = tid * PER + j;
+                    const unsigned long long got = src[e];
+                    r[q * PER + j] = (st >= 0 && e < cq) ? got : kPadAcc;  // (+inf lowers no minimum)
+                }
+            }
+        };
+        if (one_batch) {
+            if (two) load_batch(std::integral_constant<int, kPer2>{});
+            else load_batch(std::integral_constant<int, kPer4>{});
+        }
+        auto stream_pb = [&](int q) -> uint32_t {  // where stream q's 32x16 storage tile sits in the processing tile
+            const int per_row = 1 << (g.tw_shift - 5);
+            return (uint32_t)(((q >> (g.tw_shift - 5)) * 16) * tw + (q & (per_row - 1)) * 32);
+        };
         __syncthreads();  // the previous item's LDS is no longer read
         if (tid == 0) s_nseg = 0;
-        __syncthreads();
+        if (!one_batch) __syncthreads();  // workgroup-uniform
         // the contiguous pieces of this item's entries: per stream the static extent and the dynamic ones,
         // clipped to the slice [sub, sub + 1) / nsub of the stream
-        if (tid < kMaxSegs) {
+        if (!one_batch && tid < kMaxSegs) {
             const int s = tid / kDirK, k = tid % kDirK;
             const int st = s < (2 << (g.tw_shift - 5)) ? stream_tile(g, tx, ty, s) : -1;
             const unsigned long long cnt = s == 0 ? rec0.y : (s == 1 ? rec0.z : (s == 2 ? rec0.w : rec1.x));
@@ -1141,8 +1210,7 @@ __global__ __launch_bounds__(kTileThreads, 6) void k_tile(TileStore S, TileGeom 
                     const uint32_t q = atomicAdd(&s_nseg, 1u);
                     s_seg_p[q] = (unsigned long long)p;
                     s_seg_n[q] = (uint32_t)(hi - lo);
-                    const int per_row = 1 << (g.tw_shift - 5);
-                    s_seg_pb[q] = (uint32_t)(((s >> (g.tw_shift - 5)) * 16) * tw + (s & (per_row - 1)) * 32);
+                    s_seg_pb[q] = stream_pb(s);
                 }
             }
         }
@@ -1167,9 +1235,11 @@ __global__ __launch_bounds__(kTileThreads, 6) void k_tile(TileStore S, TileGeom 
             }
         }
         __syncthreads();
+        RTR_TSTAMP(1);
         const uint32_t nseg = s_nseg;
         uint32_t n_local = 0;
         for (uint32_t q = 0; q < nseg; ++q) n_local += s_seg_n[q];
+        if (one_batch) n_local = rec0.y + rec0.z + rec0.w + rec1.x;
         const bool do_min = MODE == 1 || MODE == 0;
         const bool do_acc = MODE >= 2 || (MODE == 0 && !split);
         // Accumulators: the exact layout is two 64-bit words per pixel, (c0 | c1 << 32) and
@@ -1184,15 +1254,17 @@ __global__ __launch_bounds__(kTileThreads, 6) void k_tile(TileStore S, TileGeom 
         if (do_acc)
             for (int p = tid; p < (narrow ? 2 : 4) * tpix; p += T) s_acc[p] = 0;
         auto min_one = [&](unsigned long long r, uint32_t pb) {  // render.cu:81, behind an early-z read: an LDS read
-            // costs a fraction of an LDS atomic, and only a few entries per pixel lower its minimum
+            // costs a fraction of an LDS atomic, and only a few entries per pixel lower its minimum.  (Indexing
+            // the __shared__ array itself keeps the accesses ds_ instructions: a volatile read through a
+            // derived pointer became a flat load with a full wait per entry.)
             const uint32_t d = (uint32_t)(r >> 33), px = (uint32_t)(r >> 24) & 511u;
-            uint32_t *slot = &s_depth[pb + ((px >> 5) << g.tw_shift) + (px & 31u)];
-            if (d < *reinterpret_cast<volatile uint32_t *>(slot)) atomicMin(slot, d);
+            const uint32_t idx = pb + ((px >> 5) << g.tw_shift) + (px & 31u);
+            if (d < __hip_atomic_load(&s_mem[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMin(&s_mem[idx], d);
         };
         auto acc_one = [&](unsigned long long r, uint32_t pb, bool packed) {
             const uint32_t d = (uint32_t)(r >> 33), px = (uint32_t)(r >> 24) & 511u;
             const uint32_t p = pb + ((px >> 5) << g.tw_shift) + (px & 31u);
-            const float m = __uint_as_float(s_depth[p]);
+            const float m = __uint_as_float(s_mem[p]);  // s_depth
             if (!(__uint_as_float(d) > f_add(m, window))) {  // render.cu:106, then :125-128
                 const unsigned long long c0 = r & 0xFFull, c1 = (r >> 8) & 0xFFull, c2 = (r >> 16) & 0xFFull;
                 if (packed) {
@@ -1203,28 +1275,80 @@ __global__ __launch_bounds__(kTileThreads, 6) void k_tile(TileStore S, TileGeom 
                 }
             }
         };
-        constexpr unsigned long long kPadMin = (unsigned long long)RTR_EMPTY << 33;  // never lowers a minimum
-        constexpr unsigned long long kPadAcc = 0x7F800000ull << 33;                  // +inf fails every window test
-        // Most tiles hold fewer entries than one batch of the workgroup (8 per thread): those are read
-        // ONCE and stay in registers across the barrier between the two reference passes.  The eight
-        // registers of a thread are dealt to the segments statically (2 segments: 4 each, ...), so a
-        // register's segment is workgroup-uniform.
-        const int sh = nseg <= 2u ? 2 : (nseg <= 4u ? 1 : 0);  // log2(registers per segment)
-        bool fits = MODE == 0 && !split && nseg <= (uint32_t)kTileBatch;
-        for (uint32_t q = 0; q < nseg && fits; ++q) fits = s_seg_n[q] <= (T << sh);
-        const bool one_batch = fits;
-        unsigned long long r[kTileBatch];
-        if (one_batch) {
+        // A thread's registers of one segment hold CONSECUTIVE entries of the stream, i.e. consecutive points
+        // of the cloud (T1 writes a lane's four points next to each other), which mostly fall on the same
+        // pixel: they are merged in registers first, one LDS atomic per run -- LDS atomics are what bounds
+        // this kernel (about one lane per clock and CU).
+        auto pixel_of = [&](unsigned long long e, uint32_t pb) -> uint32_t {
+            const uint32_t px = (uint32_t)(e >> 24) & 511u;
+            return pb + ((px >> 5) << g.tw_shift) + (px & 31u);
+        };
+        auto min_runs = [&](auto per_tag) {
+            constexpr int PER = decltype(per_tag)::value;
 #pragma unroll
-            for (int k = 0; k < kTileBatch; ++k) {
-                const uint32_t q = (uint32_t)k >> sh, e = tid + ((uint32_t)k & ((1u << sh) - 1u)) * T;
-                r[k] = (q < nseg && e < s_seg_n[q]) ? reinterpret_cast<const unsigned long long *>(s_seg_p[q])[e] : kPadAcc;
+            for (int k0 = 0; k0 < kTileBatch; k0 += PER) {
+                const uint32_t pb = stream_pb(k0 / PER);
+                uint32_t run_p = pixel_of(r[k0], pb), run_d = (uint32_t)(r[k0] >> 33);
+#pragma unroll
+                for (int j = 1; j < PER; ++j) {
+                    const uint32_t pj = pixel_of(r[k0 + j], pb), dj = (uint32_t)(r[k0 + j] >> 33);
+                    if (pj != run_p) {
+                        if (run_d < __hip_atomic_load(&s_mem[run_p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMin(&s_mem[run_p], run_d);
+                        run_p = pj;
+                        run_d = dj;
+                    } else {
+                        run_d = dj < run_d ? dj : run_d;
+                    }
+                }
+                if (run_d < __hip_atomic_load(&s_mem[run_p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMin(&s_mem[run_p], run_d);
             }
+        };
+        auto acc_runs = [&](auto per_tag, bool packed) {
+            constexpr int PER = decltype(per_tag)::value;
+            auto flush = [&](uint32_t p, unsigned long long v) {  // v: c0 | c1 << 16 | c2 << 32 | count << 48, <= 8 entries
+                if (v == 0ull) return;
+                if (packed) {
+                    atomicAdd(s_acc64 + p, v);
+                } else {
+                    atomicAdd(s_acc64 + 2 * p + 0, (v & 0xFFFFull) | (((v >> 16) & 0xFFFFull) << 32));
+                    atomicAdd(s_acc64 + 2 * p + 1, ((v >> 32) & 0xFFFFull) | ((v >> 48) << 32));
+                }
+            };
+            auto value_of = [&](unsigned long long e, uint32_t p) -> unsigned long long {
+                const float m = __uint_as_float(s_mem[p]);  // s_depth
+                if (__uint_as_float((uint32_t)(e >> 33)) > f_add(m, window)) return 0ull;  // render.cu:106, then :125-128
+                return (e & 0xFFull) | (((e >> 8) & 0xFFull) << 16) | (((e >> 16) & 0xFFull) << 32) | (1ull << 48);
+            };
 #pragma unroll
-            for (int k = 0; k < kTileBatch; ++k) min_one(r[k], s_seg_pb[(uint32_t)k >> sh]);  // (+inf lowers no minimum)
+            for (int k0 = 0; k0 < kTileBatch; k0 += PER) {
+                const uint32_t pb = stream_pb(k0 / PER);
+                uint32_t run_p = pixel_of(r[k0], pb);
+                unsigned long long run_v = value_of(r[k0], run_p);
+#pragma unroll
+                for (int j = 1; j < PER; ++j) {
+                    const uint32_t pj = pixel_of(r[k0 + j], pb);
+                    const unsigned long long vj = value_of(r[k0 + j], pj);
+                    if (pj != run_p) {
+                        flush(run_p, run_v);
+                        run_p = pj;
+                        run_v = vj;
+                    } else {
+                        run_v += vj;
+                    }
+                }
+                flush(run_p, run_v);
+            }
+        };
+        if (one_batch) {
+#ifdef RTR_EXPERIMENT
+            if (stamp && tid == 0 && r[0] != 1ull) ts_dbg(S)[sb + 11] = wall_clock64();  // first entry has arrived
+            if (stamp && tid == 0 && (r[3] ^ r[7]) != 1ull) ts_dbg(S)[sb + 12] = wall_clock64();  // all have
+#endif
+            if (two) min_runs(std::integral_constant<int, kPer2>{});
+            else min_runs(std::integral_constant<int, kPer4>{});
         } else if (do_min) {
             for (uint32_t q = 0; q < nseg; ++q) {
-                const unsigned long long *ent = reinterpret_cast<const unsigned long long *>(s_seg_p[q]);
+                const entries_t ent = (entries_t)s_seg_p[q];
                 const uint32_t n = s_seg_n[q], pb = s_seg_pb[q];
                 for (uint32_t e = tid; e < n; e += kTileBatch * T) {
 #pragma unroll
@@ -1234,15 +1358,17 @@ __global__ __launch_bounds__(kTileThreads, 6) void k_tile(TileStore S, TileGeom 
                 }
             }
         }
+        RTR_TSTAMP(2);
         __syncthreads();
+        RTR_TSTAMP(3);
         auto accumulate = [&](bool packed) {
             if (one_batch) {
-#pragma unroll
-                for (int k = 0; k < kTileBatch; ++k) acc_one(r[k], s_seg_pb[(uint32_t)k >> sh], packed);
+                if (two) acc_runs(std::integral_constant<int, kPer2>{}, packed);
+                else acc_runs(std::integral_constant<int, kPer4>{}, packed);
                 return;
             }
             for (uint32_t q = 0; q < nseg; ++q) {
-                const unsigned long long *ent = reinterpret_cast<const unsigned long long *>(s_seg_p[q]);
+                const entries_t ent = (entries_t)s_seg_p[q];
                 const uint32_t n = s_seg_n[q], pb = s_seg_pb[q];
                 for (uint32_t e = tid; e < n; e += kTileBatch * T) {  // (r is free here: not the one-batch case)
 #pragma unroll
@@ -1254,7 +1380,9 @@ __global__ __launch_bounds__(kTileThreads, 6) void k_tile(TileStore S, TileGeom 
         };
         if (do_acc) {
             accumulate(narrow);
+            RTR_TSTAMP(9);
             __syncthreads();
+            RTR_TSTAMP(10);
             if (narrow) {
                 int over = 0;
                 for (int p = tid; p < tpix; p += T) over |= (s_acc64[p] >> 48) > 257ull;
@@ -1267,6 +1395,7 @@ __global__ __launch_bounds__(kTileThreads, 6) void k_tile(TileStore S, TileGeom 
                 }
             }
         }
+        RTR_TSTAMP(4);
         auto sums_of = [&](int p, uint32_t &a0, uint32_t &a1, uint32_t &a2, uint32_t &c) {
             if (narrow) {
                 const unsigned long long pk = s_acc64[p];
@@ -1356,6 +1485,7 @@ __global__ __launch_bounds__(kTileThreads, 6) void k_tile(TileStore S, TileGeom 
                 }
             }
         }
+        RTR_TSTAMP(5);
         if ((MODE == 0 && !split) || (MODE == 3 && finish)) {
             __syncthreads();
             // image rows of the tile as dwords when the row segment is whole and 4-byte aligned
@@ -1374,8 +1504,10 @@ __global__ __launch_bounds__(kTileThreads, 6) void k_tile(TileStore S, TileGeom 
                     if (x < W && y < H) img[((size_t)y * W + x) * 3 + ch] = s_rgb[q];
                 }
             }
+            RTR_TSTAMP(6);
             if (pyr.enable)  // s_acc is free now (the colours were resolved into s_rgb before the barrier)
                 tile_pyramid(s_depth, s_acc, g, tx0, ty0, pyr.L, pyr.n_eff_rows, pyr.part_min, pyr.part_max, tile, tid, T);
+            RTR_TSTAMP(7);
         }
         if (MODE == 2 && pyr.enable && finish) {  // sharded frames: s_depth holds the GLOBAL minimum of the tile here
             __syncthreads();                      // the sums have been read out of s_acc

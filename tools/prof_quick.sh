@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 TAG=$1; shift
 mkdir -p $R/gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/trace -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra --no-parity "$@" > $R/gpurun_out/$TAG/bench_prof.json 2>/dev/null
+timeout -k 10 90 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/trace -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra --no-parity "$@" > $R/gpurun_out/$TAG/bench_prof.json 2>/dev/null
 python3 - <<PY
 import csv, glob
 for f in glob.glob("$R/gpurun_out/$TAG/trace/**/*kernel_stats.csv", recursive=True):
