@@ -74,11 +74,16 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          holding more entries than the threshold is processed by several workgroups, each
  *          taking a slice of at least split_slice entries (a distant overview that packs the
  *          whole cloud into a few tiles would otherwise serialise on them).
- *  "auto_reorder": 1 = every later rtr_upload_points / rtr_generate_synthetic is followed by
- *          rtr_reorder_points, best effort (skipped when the sort's scratch does not fit).  Default 0
- *          here; the drop-in classes (rtr::ProjectCloud, the Python mirror) switch it on: the
- *          reference's loader hands over 0.25 m blocks that are unordered inside, which costs ~13 %
- *          (DESIGN.md), and those classes never hand the points back.
+ *  "auto_reorder": what follows every later rtr_upload_points / rtr_generate_synthetic.  2 (default): the
+ *          cloud is Morton-sorted once (rtr_reorder_points) when its 256-point chunks are not spatially
+ *          compact -- mean chunk-box diagonal above twice what an ideally ordered volume cloud of that
+ *          size has, (256 / n)^(1/3) of the cloud's diagonal.  Scanner sweeps and Morton-like surfaces
+ *          pass; a hash-ordered cloud and the reference loader's 0.25 m blocks (unordered inside) are
+ *          sorted, which is worth 13 % ... 2.4 x per frame.  1: always, 0: never.  Best effort
+ *          (skipped when the sort's scratch does not fit); clouds under 65536 points are left alone.
+ *          Frames never depend on the point order; rtr_download_points returns the RESIDENT order, a
+ *          permutation of the uploaded one when rtr_get_option("reordered") reads 1
+ *          ("order_ratio_ppm": the measured chunk / cloud diagonal ratio in millionths).
  *  "cull": 1 = skip 256-point chunks whose bounding box is provably outside the frustum
  *          (exact: same frame; an algorithmic byte reduction, off by default and reported
  *          separately from the roofline figure; needs a spatially coherent point order).
@@ -91,8 +96,18 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          before "overlap") additionally gives the two streams disjoint CU masks, t CUs of every
  *          XCD for the tail.
  *  "point_grid": workgroups of the grid-stride point kernels (default 1024 = 4 per CU).
+ *  "phases": the point kernel's workgroups are cut into this many groups that start at different
+ *          places of the cloud (default 1: measured best); "fill_shift": the per-tile stream counters
+ *          lie 4 << value bytes apart (default 2; packed counters share memory channels and queue up).
+ *  "p2p_timeout_ms": how long a flag barrier of the peer-to-peer exchange (section 5b) waits for a rank
+ *          that does not arrive before it flags the frame in rtr_p2p_status (default 2000).
+ *  "xp": only in RTR_EXPERIMENT builds (make experiment): switches parts of the point kernel off for
+ *          timing attribution -- frames are WRONG while it is non-zero; the shipped library rejects it.
  *  "probe_variant": measurement aid of tools/probe_variants.py (selects the rtr_stream_probe kernel). */
 int rtr_set_option(rtr_ctx *ctx, const char *key, int value);
+/* Reads an option back; also "reordered" (1: the resident cloud was sorted by the library) and
+ * "order_ratio_ppm" (mean chunk-box diagonal / cloud diagonal as uploaded, in millionths). */
+int rtr_get_option(rtr_ctx *ctx, const char *key, int *value);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's
  * own non-blocking stream; NULL means HIP's default stream.  rtr_reset_stream returns to the
  * private stream. */
@@ -115,10 +130,11 @@ int rtr_generate_synthetic(rtr_ctx *ctx, int scene, uint64_t seed, uint64_t firs
 /* One-off Morton (Z-order) sort of the resident cloud: consecutive points become spatial
  * neighbours, like the reference loader's 0.25 m block order (cloudreader.cpp:8-82).  Never
  * changes a frame (min and integer sums commute); it changes rtr_download_points' order and
- * makes the tile sort cheap and option "cull" effective. */
+ * makes the per-tile appends long runs and option "cull" effective. */
 int rtr_reorder_points(rtr_ctx *ctx);
 int rtr_num_points(const rtr_ctx *ctx, uint64_t *n);
-/* Copies the resident cloud back as float4 / uchar4 AoS (tests, debugging). */
+/* Copies the resident cloud back as float4 / uchar4 AoS (tests, debugging), in the RESIDENT order (see
+ * option "auto_reorder"). */
 int rtr_download_points(rtr_ctx *ctx, float *xyzw, uint8_t *rgba, uint64_t first, uint64_t count);
 
 /* ---- 3. camera (project_cloud.cu:318, project_cloud.h:50-59) -------------------- */
@@ -164,8 +180,10 @@ int rtr_filter(rtr_ctx *ctx);                          /* project_cloud.cu:331-3
  *   -> rtr_accumulate_pass -> rtr_p2p_sum_resolve             (RTR_BUF_IMAGE := resolve(SUM of
  *   RTR_BUF_ACCUM over ranks); RTR_BUF_ACCUM itself stays local) -> rtr_filter (optional)
  * All ranks must issue the same sequence of rtr_p2p_* calls.  A rank that does not arrive
- * within the barrier timeout (2 s) is flagged in rtr_p2p_status; the frame is then undefined and
- * the caller should fall back to the collectives.  rtr_set_resolution closes the mapping. */
+ * within the barrier timeout (option "p2p_timeout_ms", default 2 s) is flagged in rtr_p2p_status on the
+ * ranks that waited for it; their frames since then are undefined.  The caller polls rtr_p2p_status
+ * (a host word, no synchronisation), agrees with the other ranks and falls back to the collectives --
+ * sharded.ShardedProjector does that every `check_every` frames.  rtr_set_resolution closes the mapping. */
 #define RTR_P2P_MAX_RANKS 16
 typedef struct rtr_p2p_handles {
     unsigned char depth[64], accum[64], image[64], reduced[64], flags[64], tiles[64];

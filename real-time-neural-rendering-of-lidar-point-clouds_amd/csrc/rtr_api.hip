@@ -67,12 +67,16 @@ struct rtr_ctx {
     bool force_atomic = false;       // set around a whole frame that takes the atomic form (> 4096 tiles)
     int opt_heavy = 32768;           // tiles with more entries are split over several workgroups in T4 ...
     int opt_slice = 16384;           // ... into slices of at least this many entries
+    int opt_p2p_timeout_ms = 2000;   // peer-to-peer flag barriers give up after this long (option "p2p_timeout_ms")
     int opt_fill_shift = 2;          // stream counters 2^2 words = 16 B apart (see "fill_shift")
     int opt_xp = 0;                  // RTR_EXPERIMENT builds only (tools/kbench.py)
     int opt_phases = 1;         // T1: phase groups of the grid stride (option "phases", see k_project_bin)
     int opt_probe = 0;          // rtr_stream_probe variant (experiments)
     int opt_cull = 0;           // per-chunk frustum culling in T1
-    int opt_auto_reorder = 0;   // Morton-sort every cloud right after upload / generation
+    int opt_auto_reorder = 2;   // Morton-sort a cloud right after upload / generation: 0 never, 1 always, 2 when its
+                                // 256-point chunks are not spatially compact (default)
+    bool reordered = false;     // the resident cloud was sorted by the library
+    float order_ratio = 0.f;    // mean chunk diagonal / cloud diagonal as uploaded
     int opt_grid = rtr::kDefaultPointGrid;  // workgroups of the point kernels
 
     // peer-to-peer exchange (rtr_p2p_*): own exchange buffers, the peers' mappings, barrier state
@@ -547,6 +551,11 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
         c->list_valid = false;
         return RTR_OK;
     }
+    if (!strcmp(key, "p2p_timeout_ms")) {
+        NEED(c, value >= 1 && value <= 60000, "p2p_timeout_ms must be in 1..60000");
+        c->opt_p2p_timeout_ms = value;
+        return RTR_OK;
+    }
     if (!strcmp(key, "phases")) {  // T1: wave groups that start at different places of the cloud (k_project_bin)
         NEED(c, value >= 1 && value <= 65535, "phases must be in 1..65535");
         c->opt_phases = value;
@@ -560,7 +569,8 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
         return RTR_OK;
     }
     if (!strcmp(key, "auto_reorder")) {
-        c->opt_auto_reorder = value != 0;
+        NEED(c, value >= 0 && value <= 2, "auto_reorder must be 0 (never), 1 (always) or 2 (when the order is incoherent)");
+        c->opt_auto_reorder = value;
         return RTR_OK;
     }
     if (!strcmp(key, "cull")) {
@@ -583,6 +593,22 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
         return RTR_OK;
     }
     return fail(c, RTR_ERR_INVALID, "unknown option '%s'", key);
+}
+
+int rtr_get_option(rtr_ctx *c, const char *key, int *value) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, key != nullptr && value != nullptr, "key / value is NULL");
+    if (!strcmp(key, "mode")) *value = c->opt_mode;
+    else if (!strcmp(key, "auto_reorder")) *value = c->opt_auto_reorder;
+    else if (!strcmp(key, "reordered")) *value = c->reordered ? 1 : 0;  // the resident cloud was sorted by the library
+    else if (!strcmp(key, "order_ratio_ppm")) *value = (int)(c->order_ratio * 1e6f);  // chunk / cloud diagonal as uploaded
+    else if (!strcmp(key, "cull")) *value = c->opt_cull;
+    else if (!strcmp(key, "keep_accum")) *value = c->opt_keep_accum;
+    else if (!strcmp(key, "split_threshold")) *value = c->opt_heavy;
+    else if (!strcmp(key, "split_slice")) *value = c->opt_slice;
+    else if (!strcmp(key, "point_grid")) *value = c->opt_grid;
+    else return fail(c, RTR_ERR_INVALID, "unknown option '%s'", key);
+    return RTR_OK;
 }
 
 int rtr_stream_probe(rtr_ctx *c, const float P[16]) {
@@ -627,10 +653,29 @@ int rtr_synchronize(rtr_ctx *c) {
 
 // ---- cloud -------------------------------------------------------------------------
 
-// Option "auto_reorder": best effort.  The sort works on scratch copies and only writes the cloud
-// back at the very end, so a cloud too large for the scratch (or for hipcub's 2^31 item limit)
-// simply stays in the order it was uploaded in.
+// Option "auto_reorder" (after every upload / generation; the chunk bounds are current).  2 (default):
+// sort when the 256-point chunks are not spatially compact -- mean chunk diagonal more than twice what
+// an ideally ordered VOLUME cloud of this size would have, (256 / n)^(1/3) of the cloud's diagonal.
+// A scanner's sweep order or the reference loader's Morton-like surfaces pass; a hash-ordered cloud
+// (ratio ~1) and the reference's 0.25 m blocks that are unordered inside do not.  Frames never depend
+// on the point order; rtr_download_points returns the resident (possibly sorted) order.
+// Best effort: the sort works on scratch copies and only writes the cloud back at the very end, so a
+// cloud too large for the scratch simply stays in the order it was uploaded in.
 static int auto_reorder(rtr_ctx *c) {
+    c->reordered = false;
+    c->order_ratio = 0.f;
+    if (c->opt_auto_reorder == 0 || c->n < 2) return RTR_OK;
+    bool want = c->opt_auto_reorder == 1;
+    if (!want && c->n >= (1u << 16)) {  // (tiny clouds render in microseconds whatever their order)
+        float ratio = 0.f;
+        if (rtr::order_quality(c->stream, c->bounds, c->n, &ratio) != 0) {
+            (void)hipGetLastError();
+            return RTR_OK;
+        }
+        c->order_ratio = ratio;
+        want = ratio > 2.0f * cbrtf(256.0f / (float)c->n);
+    }
+    if (!want) return RTR_OK;
     if (rtr_reorder_points(c) != RTR_OK) (void)hipGetLastError();
     return RTR_OK;
 }
@@ -668,7 +713,7 @@ int rtr_upload_points(rtr_ctx *c, const float *xyz, size_t xs, const uint8_t *rg
     rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
     HIP_TRY(c, sync_streams(c));
     if (int rc2 = launch_check(c, "aos_to_soa")) return rc2;
-    return c->opt_auto_reorder ? auto_reorder(c) : RTR_OK;
+    return auto_reorder(c);
 }
 
 int rtr_generate_synthetic(rtr_ctx *c, int scene, uint64_t seed, uint64_t first, uint64_t count, uint64_t total) {
@@ -686,7 +731,7 @@ int rtr_generate_synthetic(rtr_ctx *c, int scene, uint64_t seed, uint64_t first,
     rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
     HIP_TRY(c, sync_streams(c));
     if (int rc2 = launch_check(c, "generate")) return rc2;
-    return c->opt_auto_reorder ? auto_reorder(c) : RTR_OK;
+    return auto_reorder(c);
 }
 
 int rtr_reorder_points(rtr_ctx *c) {
@@ -696,6 +741,7 @@ int rtr_reorder_points(rtr_ctx *c) {
     c->list_valid = false;
     int e = rtr::reorder_morton(c->stream, c->x, c->y, c->z, c->rgba, c->n);
     if (e != 0) return fail(c, RTR_ERR_HIP, "reorder failed: %s", hipGetErrorString((hipError_t)e));
+    c->reordered = true;
     rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
     HIP_TRY(c, sync_streams(c));
     return launch_check(c, "reorder");
@@ -1098,10 +1144,10 @@ int rtr_p2p_status(rtr_ctx *c, uint32_t *barrier_timeouts) {
 }
 
 namespace {
-constexpr unsigned long long kP2PTimeoutTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
 void p2p_barrier(rtr_ctx *c) {
     auto &q = c->p2p;
-    rtr::launch_p2p_sync(c->stream, q.flags, q.flags_of, q.rank, q.world, ++q.seq, q.status_dev, kP2PTimeoutTicks);
+    const unsigned long long ticks = 100000ull * (unsigned long long)c->opt_p2p_timeout_ms;  // 100 MHz wall clock
+    rtr::launch_p2p_sync(c->stream, q.flags, q.flags_of, q.rank, q.world, ++q.seq, q.status_dev, ticks);
 }
 }  // namespace
 

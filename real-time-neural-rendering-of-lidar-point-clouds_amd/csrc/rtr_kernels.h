@@ -136,6 +136,8 @@ void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int
                         const float *bounds, int clear_split, int phases, int xp = 0);
 void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds);  // 6 floats per 256 points
 int reorder_morton(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, uint64_t n);  // rtr_reorder.hip
+// mean diagonal of the 256-point chunk boxes / diagonal of the cloud's box, from launch_chunk_bounds' output
+int order_quality(hipStream_t s, const float *bounds, uint64_t n, float *ratio);
 // T4: per-tile LDS z-buffer over the tile store.  mode 0 = whole frame (min + accumulate + resolve
 // of every unsplit tile, min phase of split tiles), 3 = second phase of the split tiles of a whole
 // frame, 1 = min only, 2 = accumulate only.

@@ -3,10 +3,13 @@
 // neighbours.  This is what the reference's loader does at 0.25 m granularity with its block
 // grid (cloudreader.cpp:8-82); the projector's output does not depend on point order
 // (render.cu:81,125-128 commute), only its speed does: coherent order makes the tile sort
-// (T3) write long runs and lets whole 256-point chunks be frustum-culled.
-// The radix sort is rocPRIM's (hipcub); everything in the per-frame path is hand-written.
+// append one run per wave and tile and lets whole 256-point chunks be frustum-culled.
+// The radix sort is rocPRIM's (called directly); everything in the per-frame path is hand-written.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <cstdint>
 
@@ -95,12 +98,87 @@ __global__ __launch_bounds__(256) void k_gather(const uint32_t *__restrict__ per
     }
 }
 
+// How spatially compact the 256-point chunks are: sum of the chunk boxes' diagonals, number of
+// chunks with a finite box, and the cloud's bounding box -- all from the chunk bounds
+// (k_chunk_bounds), i.e. 24 bytes per 256 points.
+__global__ __launch_bounds__(256) void k_order_quality(const float *__restrict__ bounds, uint64_t nchunks,
+                                                       float *__restrict__ sum_diag, uint32_t *__restrict__ finite,
+                                                       uint32_t *__restrict__ bb) {
+    float sum = 0.f;
+    uint32_t cnt = 0;
+    uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    for (uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x; c < nchunks; c += (uint64_t)gridDim.x * 256) {
+        const float *b = bounds + 6 * c;
+        const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+        if (d == d && d < 3.0e38f) {  // finite (an empty or non-finite chunk has an infinite / NaN box)
+            sum += d;
+            cnt += 1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t a = f2ord(b[k]), e = f2ord(b[3 + k]);
+                lo[k] = a < lo[k] ? a : lo[k];
+                hi[k] = e > hi[k] ? e : hi[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off, 64);
+        cnt += __shfl_xor(cnt, off, 64);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t a = __shfl_xor(lo[k], off, 64), e = __shfl_xor(hi[k], off, 64);
+            lo[k] = a < lo[k] ? a : lo[k];
+            hi[k] = e > hi[k] ? e : hi[k];
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(sum_diag, sum);
+        atomicAdd(finite, cnt);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            atomicMin(&bb[k], lo[k]);
+            atomicMax(&bb[3 + k], hi[k]);
+        }
+    }
+}
+
 }  // namespace
+
+// mean chunk diagonal / cloud diagonal (0 when undefined); returns a hipError_t as int
+int order_quality(hipStream_t s, const float *bounds, uint64_t n, float *ratio) {
+    *ratio = 0.f;
+    const uint64_t nchunks = ((n + 3) / 4 + 63) / 64;
+    if (nchunks == 0) return 0;
+    struct Out { float sum; uint32_t finite; uint32_t bb[6]; } h, *d = nullptr;
+    const Out init{0.f, 0u, {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u}};
+    hipError_t e = hipMalloc((void **)&d, sizeof(Out));
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(d, &init, sizeof init, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        const unsigned grid = (unsigned)((nchunks + 255) / 256 < 1024 ? (nchunks + 255) / 256 : 1024);
+        hipLaunchKernelGGL(k_order_quality, dim3(grid), dim3(256), 0, s, bounds, nchunks, &d->sum, &d->finite, d->bb);
+        e = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) return (int)e;
+    if (h.finite == 0 || !(h.bb[0] <= h.bb[3])) return 0;
+    float ext2 = 0.f;
+    for (int k = 0; k < 3; ++k) {
+        const float ext = ord2f(h.bb[3 + k]) - ord2f(h.bb[k]);
+        ext2 += ext * ext;
+    }
+    const float cloud = sqrtf(ext2);
+    if (cloud > 0.f) *ratio = (h.sum / (float)h.finite) / cloud;
+    return 0;
+}
 
 // Sorts the n points in place (through scratch copies).  Returns a hipError_t as int.
 int reorder_morton(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, uint64_t n) {
     if (n < 2) return 0;
-    if (n >= (1ull << 31)) return (int)hipErrorInvalidValue;  // hipcub item counts are int
+    if (n >= (1ull << 32)) return (int)hipErrorInvalidValue;  // the permutation is 32-bit
     uint32_t *bb = nullptr;
     uint64_t *k0 = nullptr, *k1 = nullptr;
     uint32_t *v0 = nullptr, *v1 = nullptr;
@@ -131,9 +209,9 @@ int reorder_morton(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, 
             ok(hipMalloc((void **)&v1, n * 4))) {
             hipLaunchKernelGGL(k_keys, dim3(grid), dim3(256), 0, s, x, y, z, n, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2],
                                k0, v0);
-            ok(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0, k1, v0, v1, (int)n, 0, 63, s));
+            ok(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, v0, v1, (size_t)n, 0u, 63u, s));
             if (ok(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1)))
-                ok(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k0, k1, v0, v1, (int)n, 0, 63, s));
+                ok(rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, (size_t)n, 0u, 63u, s));
         }
     }
     if (e == hipSuccess && ok(hipMalloc((void **)&tx, n * 4)) && ok(hipMalloc((void **)&ty, n * 4)) &&

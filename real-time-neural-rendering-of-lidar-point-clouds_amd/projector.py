@@ -81,6 +81,13 @@ class Projector:
     def set_option(self, key, value):
         self._chk(self._lib.rtr_set_option(self._ctx, key.encode(), int(value)))
 
+    def get_option(self, key):
+        """Current value of an option; also "reordered" (the resident cloud was sorted by the library) and
+        "order_ratio_ppm" (mean 256-point-chunk diagonal / cloud diagonal as uploaded, in 1e-6)."""
+        v = C.c_int()
+        self._chk(self._lib.rtr_get_option(self._ctx, key.encode(), C.byref(v)))
+        return v.value
+
     def stream_probe(self, P):
         P = self._P(P)
         self._chk(self._lib.rtr_stream_probe(self._ctx, _vp(P)))

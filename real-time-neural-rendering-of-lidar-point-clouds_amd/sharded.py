@@ -18,7 +18,12 @@ Exchange forms:
                          (MIN of depth, SUM + resolve of colour), four flag barriers per frame, no
                          host round trip.  The first frame is rendered both ways and compared on
                          every rank; any difference, error or barrier timeout drops back to the
-                         collectives for good.
+                         collectives for good.  In steady state every `check_every`-th frame ends with
+                         a look at the barrier-timeout word (a mapped host word, set by a barrier that
+                         gave up on a stalled rank -- the frames of the ranks that waited are then
+                         undefined) and an agreement over all ranks: if any rank saw a timeout, all
+                         drop to the collectives and that frame is rendered again with them
+                         (`p2p_suspect_frames` names the frames since the previous clean check).
 Colour forms of the collective exchange:
   "allreduce"      all-reduce SUM of the 16 B/px accumulators, every rank resolves all pixels;
   "reduce_scatter" reduce-scatter SUM (each rank receives 1/N of the pixels), slice-local
@@ -125,8 +130,13 @@ class ShardedProjector:
     `HipLocal` in production, an oracle-backed stand-in in the CPU tests.  The
     "reduce_scatter" colour form additionally needs resolve_range() and image_tensor()."""
 
-    def __init__(self, local, group=None, colour="allreduce", force_exchange=False, exchange="collective"):
+    def __init__(self, local, group=None, colour="allreduce", force_exchange=False, exchange="collective",
+                 check_every=16):
         assert colour in ("allreduce", "reduce_scatter") and exchange in ("collective", "p2p")
+        assert check_every >= 1
+        self.check_every = check_every  # p2p: frames between two looks at the barrier-timeout word (1 = every frame)
+        self.frame_no = 0               # p2p frames rendered since the exchange was verified
+        self.p2p_suspect_frames = None  # (first, last) frame_no that may be undefined after a barrier timeout
         self.exchange = exchange
         self.p2p_note = None        # why the p2p exchange was dropped, if it was
         self._p2p_res = None        # resolution the peers' buffers are mapped for
@@ -194,8 +204,19 @@ class ShardedProjector:
                 self._drop_p2p("first frame differed from the collectives' (or a barrier timed out)")
                 return False
             self._p2p_verified = True
+            self.frame_no = 0
         else:
             lo.p2p_render(P, with_filter)  # the whole sequence in one library call
+            self.frame_no += 1
+            if self.frame_no % self.check_every == 0:
+                # did a barrier give up on a stalled rank since the last check?  The word is host memory; what
+                # costs is the agreement (one small all-reduce + host sync), hence only every check_every frames.
+                lo.p.synchronize()  # this rank's frames up to here have run (or timed out)
+                if not self._all_agree(lo.p2p_timeouts() == 0):
+                    self.p2p_suspect_frames = (self.frame_no - self.check_every + 1, self.frame_no)
+                    self._drop_p2p("a flag barrier timed out (a rank stalled): frames %d..%d since the last clean check "
+                                   "may be undefined on the ranks that waited" % self.p2p_suspect_frames)
+                    return False  # the caller renders this frame again with the collectives
             return True
         if with_filter:
             lo.filter()

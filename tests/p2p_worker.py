@@ -17,6 +17,7 @@ import __graft_entry__ as entry  # noqa: E402
 def main():
     W, H, n, frames = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     scene, mode = sys.argv[5], int(sys.argv[6])
+    stall_rank = int(sys.argv[7]) if len(sys.argv) > 7 else -1  # this rank sleeps past the barrier timeout once
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     pkg, orc = entry.load_package(), entry.load_oracle()
@@ -27,12 +28,18 @@ def main():
     proj.set_resolution(W, H)
     local = pkg.sharded.HipLocal(proj)
     local.bind_stream()
-    sp = pkg.ShardedProjector(local, colour="reduce_scatter", exchange="p2p")
+    if stall_rank >= 0:
+        proj.set_option("p2p_timeout_ms", 150)
+    sp = pkg.ShardedProjector(local, colour="reduce_scatter", exchange="p2p", check_every=1 if stall_rank >= 0 else 16)
     xyzw, rgba = orc.generate(scene, 11, 0, n, n)
     ok, notes = True, []
     for k in range(frames):
         P = pkg.orbit_projection(7 * k, W, H)
         filt = (k % 2 == 1) and W % 16 == 0
+        if k == 3 and rank == stall_rank:
+            import time
+            proj.synchronize()
+            time.sleep(1.0)  # the other ranks' barriers give up after 150 ms
         sp.render(P, filt)
         ref = orc.project(xyzw, rgba, P, W, H)
         rd, ri = ref["depth_bits"], ref["img"]
@@ -44,7 +51,7 @@ def main():
             ok = False
             notes.append("frame %d differs on rank %d" % (k, rank))
     out = {"rank": rank, "ok": ok, "exchange": sp.exchange, "p2p_note": sp.p2p_note, "timeouts": proj.p2p_timeouts(),
-           "notes": notes}
+           "notes": notes, "suspect": sp.p2p_suspect_frames}
     gathered = [None] * world
     dist.all_gather_object(gathered, out)
     if rank == 0:

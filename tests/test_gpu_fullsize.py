@@ -26,6 +26,7 @@ def test_c3_full_size_against_oracle(pkg, orc, scene):
     import torch
     p = pkg.Projector(0)
     try:
+        p.set_option("auto_reorder", 0)  # the generator's own order (checked slice by slice below)
         p.generate_synthetic(scene, 0xC0FFEE03, 0, N, N)
         p.set_resolution(W, H)
         P = pkg.orbit_projection(17, W, H)
@@ -89,6 +90,12 @@ def test_c3_full_size_against_oracle(pkg, orc, scene):
             p.synchronize()
             acc += torch.as_tensor(p.device_buffer(pkg._lib.BUF_ACCUM, "<i4"), device="cuda")
         assert torch.equal(acc, acc_full)
+        # the default upload policy at full size: the hash-ordered box is sorted, the room is left alone
+        p.set_option("auto_reorder", 2)
+        p.generate_synthetic(scene, 0xC0FFEE03, 0, N, N)
+        assert bool(p.get_option("reordered")) == (scene == "uniform_box")
+        img3, depth3 = p.project(P)
+        assert np.array_equal(img3, img) and np.array_equal(depth3.view(np.uint32), depth.view(np.uint32))
     finally:
         p.close()
 

@@ -23,8 +23,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("extra", [[], ["--scaling", "strong", "--colour", "allreduce", "--pipeline", "1"]],
-                         ids=["weak-rs-pipelined", "strong-allreduce"])
+@pytest.mark.parametrize("extra", [[], ["--scaling", "weak", "--colour", "allreduce", "--pipeline", "1"]],
+                         ids=["strong-rs-pipelined", "weak-allreduce"])
 def test_two_rank_bench_matches_oracle(extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend",
@@ -35,7 +35,12 @@ def test_two_rank_bench_matches_oracle(extra):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["parity_vs_oracle"] is True
     assert out["parity_vs_single_gpu"] is True   # rank 0 renders the whole cloud alone and compares
-    assert out["config"]["points_total"] == (3_000_000 if "strong" in extra else 6_000_000)
+    # default = BASELINE C4's regime: the SAME cloud sharded over the ranks, the weak figure as an extra key
+    assert out["scaling"] == ("weak" if "weak" in extra else "strong")
+    assert out["config"]["points_total"] == (6_000_000 if "weak" in extra else 3_000_000)
+    if "weak" not in extra:
+        assert out["weak_scaling"]["points_total"] == 6_000_000 and out["weak_scaling"]["value"] > 0
+    assert "multi-GPU box" in out["multi_gpu_note"]
     assert out["roofline"]["bound"] == "hbm" and out["value"] > 0
     # --exchange auto: the collectives are timed first, then the hand-written peer-to-peer exchange,
     # which must have matched them before and after its timed frames on both ranks

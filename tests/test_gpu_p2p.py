@@ -41,6 +41,25 @@ def test_p2p_exchange_matches_oracle(ranks, W, H, scene, mode):
         assert r["exchange"] == "p2p" and r["timeouts"] == 0, r
 
 
+def test_p2p_barrier_timeout_falls_back_to_the_collectives():
+    """One rank stalls for a second while the barrier timeout is 150 ms: the ranks that waited flag the
+    frame, every rank agrees at the end of that frame (check_every = 1), the exchange drops to the
+    collectives, the frame is rendered again -- and every frame still equals the oracle's."""
+    ranks = 3
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "p2p_worker.py"), "640", "480",
+           "400000", "7", "room_shell", "1", "1"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("[")][-1])
+    assert len(out) == ranks
+    for r in out:
+        assert r["ok"], r
+        assert r["exchange"] == "collective" and "timed out" in (r["p2p_note"] or ""), r
+        assert r["suspect"] is not None, r
+    assert any(r["timeouts"] != 0 for r in out if r["rank"] != 1), out  # a rank that waited saw it
+
+
 def test_p2p_single_rank_and_misuse(pkg, orc):
     """world = 1 needs no peer mapping: the p2p calls must then leave the frame of the plain phase
     sequence; and the documented misuse cases return errors instead of touching memory."""

@@ -358,20 +358,42 @@ def test_adversarial_floats(pkg, orc, projector, mode):
 
 
 def test_auto_reorder_option(pkg, orc):
+    """Option "auto_reorder": 1 always sorts; 2 (the default) sorts a hash-ordered cloud but leaves a
+    spatially ordered one and tiny clouds alone; 0 never sorts.  Frames are the same in every case."""
     n, W, H = 100_000, 320, 240
     xyzw, rgba = orc.generate("uniform_box", 6, 0, n, n)
     P = pkg.orbit_projection(64, W, H)
     ref = orc.project(xyzw, rgba, P, W, H)
     p = pkg.Projector(0)
     try:
-        p.set_option("auto_reorder", 1)
-        p.set_option("cull", 1)
-        p.upload_points(xyzw, rgba)
-        back, _ = p.download_points()
-        assert not np.array_equal(back, xyzw)  # the resident order is the Morton order now
-        p.set_resolution(W, H)
-        img, depth = p.project(P)
-        assert np.array_equal(img, ref["img"]) and np.array_equal(depth.view(np.uint32), ref["depth_bits"])
+        assert p.get_option("auto_reorder") == 2  # the default
+        for policy, expect in ((1, True), (2, True), (0, False)):
+            p.set_option("auto_reorder", policy)
+            p.set_option("cull", 1)
+            p.upload_points(xyzw, rgba)
+            back, _ = p.download_points()
+            assert bool(p.get_option("reordered")) == expect, policy
+            assert np.array_equal(back, xyzw) == (not expect)  # the resident order is the Morton order when sorted
+            p.set_resolution(W, H)
+            img, depth = p.project(P)
+            assert np.array_equal(img, ref["img"]) and np.array_equal(depth.view(np.uint32), ref["depth_bits"])
+        p.set_option("auto_reorder", 2)
+        # a Morton-ordered surface cloud and a tiny hash-ordered one stay as they are
+        xs, cs = orc.generate("room_shell", 6, 0, n, n)
+        p.upload_points(xs, cs)
+        assert p.get_option("reordered") == 0 and p.get_option("order_ratio_ppm") > 0
+        p.upload_points(xyzw[:5000], rgba[:5000])
+        assert p.get_option("reordered") == 0
+        # the reference loader's order: 0.25 m blocks, unordered inside (cloudreader.cpp:8-82), at a size where
+        # that is visibly looser than an ideal order
+        big, cb = orc.generate("room_shell", 7, 0, 4_000_000, 4_000_000)
+        cell = np.floor(big[:, :3] / 0.25).astype(np.int64)
+        key = (cell[:, 0] * 73856093) ^ (cell[:, 1] * 19349663) ^ (cell[:, 2] * 83492791)
+        order = np.lexsort((np.random.default_rng(3).permutation(len(big)), key))
+        p.upload_points(big[order], cb[order])
+        ratio_blocks = p.get_option("order_ratio_ppm")
+        p.upload_points(big, cb)
+        assert p.get_option("order_ratio_ppm") < ratio_blocks
     finally:
         p.close()
 
