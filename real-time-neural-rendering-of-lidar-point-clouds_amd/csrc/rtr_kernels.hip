@@ -809,20 +809,19 @@ __global__ __launch_bounds__(kBlock, 4) void k_project_bin(const float4 *__restr
         // another one at the end of a divergent block is waited for right there, which turned one round
         // trip per quad into five
         const uint4 col = rgba4[i];
-        // group by storage tile; group `it` is claimed by lane `it`
-        // (the claiming lane is the group's first lane: lanes past the end of the cloud are inactive here)
+        // group by storage tile; group `it` is claimed by lane `it` (every lane is active here: the callers mask
+        // points past the end of the cloud with `live` instead of branching around them)
         int grp[4] = {-1, -1, -1, -1};
         uint32_t rank[4] = {0, 0, 0, 0};
+        uint32_t covered = 0;
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wuninitialized"
 #pragma clang diagnostic ignored "-Wsometimes-uninitialized"
         uint32_t claim[kMaxGroups];  // only the claiming lane's value is ever read (readlane below)
 #pragma clang diagnostic pop
-        int leader[kMaxGroups];
         int ng = 0;
 #pragma unroll
         for (int it = 0; it < kMaxGroups; ++it) {
-            leader[it] = 0;
             const int kk = pm[0] ? 0 : (pm[1] ? 1 : (pm[2] ? 2 : (pm[3] ? 3 : -1)));
             if (kk < 0) continue;  // wave-uniform
             const unsigned long long pk = kk == 0 ? pm[0] : (kk == 1 ? pm[1] : (kk == 2 ? pm[2] : pm[3]));
@@ -847,9 +846,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_project_bin(const float4 *__restr
                     grp[k] = it;
                     rank[k] = lower++;
                 }
-            if (lane == first && !RTR_XP(2)) claim[it] = atomicAdd(fill + ((size_t)lead << S.fill_shift), total);
-            leader[it] = first;
+            if (lane == it && !RTR_XP(2)) claim[it] = atomicAdd(fill + ((size_t)lead << S.fill_shift), total);
             ng = it + 1;
+            covered += total;
+            if (it == 3 && covered <= 8u) {            // four tiles, at most two points each: an incoherent cloud (or a
+                pm[0] = pm[1] = pm[2] = pm[3] = 0ull;  // sliver of the frustum's edge); more rounds cost more than they
+            }                                          // save -- the remaining points claim per lane below
         }
         // whatever is left belongs to a fourth, fifth, ... tile: one claim per point
 #pragma unroll
@@ -861,7 +863,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_project_bin(const float4 *__restr
         uint32_t base[kMaxGroups];
 #pragma unroll
         for (int it = 0; it < kMaxGroups; ++it)
-            base[it] = it < ng ? (uint32_t)__builtin_amdgcn_readlane((int)claim[it], leader[it]) : 0u;
+            base[it] = it < ng ? (uint32_t)__builtin_amdgcn_readlane((int)claim[it], it) : 0u;
         const uint32_t cs[4] = {col.x, col.y, col.z, col.w};
         uint32_t v[4];
         bool dyn = false;
@@ -981,12 +983,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_project_bin(const float4 *__restr
                 const int l = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
                 const uint32_t i = chunk_of(g0 + (uint32_t)l) * 64u + (uint32_t)lane;
-                if (i < n4) {
-                    const float4 X = ld_stream(x4 + i), Y = ld_stream(y4 + i), Z = ld_stream(z4 + i);
-                    Rows r;
-                    project_rows(X, Y, Z, r);
-                    do_quad(i, true, r);
-                }
+                const bool live = i < n4;  // (lanes past the end of the cloud re-read its last quad, masked)
+                const uint32_t ic = live ? i : n4 - 1u;
+                const float4 X = ld_stream(x4 + ic), Y = ld_stream(y4 + ic), Z = ld_stream(z4 + ic);
+                Rows r;
+                project_rows(X, Y, Z, r);
+                do_quad(ic, live, r);
             }
         }
     }

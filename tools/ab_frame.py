@@ -20,6 +20,9 @@ for path in sys.argv[1:]:
     ctx = C.c_void_p()
     assert L.rtr_create(C.byref(ctx), 0) == 0
     assert L.rtr_generate_synthetic(ctx, 1 if scene == "room_shell" else 0, 0xC0FFEE03, 0, n, n) == 0
+    if os.environ.get("AB_REORDER"):
+        L.rtr_reorder_points.argtypes = [C.c_void_p]
+        assert L.rtr_reorder_points(ctx) == 0
     assert L.rtr_set_resolution(ctx, W, H) == 0
     libs.append((os.path.basename(path), L, ctx))
 for rnd in range(3):
