@@ -146,3 +146,50 @@ def test_trajectory_sweep_against_oracle(pkg, orc, scene):
             assert np.array_equal(img, ref["img"]), (scene, k)
     finally:
         p.close()
+
+
+def test_c5_single_gpu_share_4k_and_colmap_replay(pkg, orc, tmp_path):
+    """One GPU's share of BASELINE config C5: points [0, 1.25e8) of the 1e9-point room_shell cloud ->
+    3840x2160 + prefilter.  (a) one pose against the multi-thread oracle on the host: depth, image, mask
+    and fp16 tensor bit for bit; (b) 100 poses of the 1000-pose orbit replayed from COLMAP
+    cameras.txt / images.txt through the drop-in class (computeFilteredRGBD, host outputs), every 10th
+    frame checked against the oracle."""
+    F = pkg.formats
+    n, total, W4, H4 = 125_000_000, 1_000_000_000, 3840, 2160
+    cal = pkg.benchmark_calibration(W4, H4)
+    F.write_cameras_txt(tmp_path / "cameras.txt", cal)
+    # (poses 200..299 of the orbit look at the x = -4 wall, which this share of the cloud holds)
+    F.write_images_txt(tmp_path / "images.txt", [pkg.orbit_pose(k) for k in range(200, 300)])
+    cal_back = F.load_calibration(tmp_path / "cameras.txt")
+    poses = [E for E, _ in F.read_trajectory_colmap(tmp_path / "images.txt")]
+    assert (cal_back.getWidth(), cal_back.getHeight()) == (W4, H4) and len(poses) == 100
+    pc = pkg.ProjectCloud(np.zeros((0, 4), np.float32), np.zeros((0, 4), np.uint8))
+    p = pc.projector
+    try:
+        p.generate_synthetic("room_shell", 0xC0FFEE05, 0, n, total)
+        xyzw, rgba = p.download_points()
+        mt = orc.MTProjector(W4, H4, _threads())
+        rgb = np.empty((H4, W4, 3), np.uint8)
+        depth = np.empty((H4, W4), np.float32)
+        checked = 0
+        for k, E in enumerate(poses):
+            assert pc.computeFilteredRGBD(cal_back, E, rgb, depth) == 1
+            if k % 10:
+                continue
+            P = orc.compose_projection(cal_back.getIntrinsicsMatrix(), E)
+            ref = mt.project(xyzw, rgba, P)
+            rf = orc.filter(ref["depth_bits"], ref["img"])
+            assert np.array_equal(depth.view(np.uint32), rf["depth"].view(np.uint32)), k
+            assert np.array_equal(rgb, rf["img"]), k
+            if k == 0:  # (a): everything the consumer sees, plus the unfiltered frame
+                assert np.array_equal(p.download(pkg._lib.BUF_MASK), rf["mask"])
+                assert np.array_equal(p.download(pkg._lib.BUF_TENSOR).reshape(5, H4, W4), rf["tensor"])
+                assert np.array_equal(p.download(pkg._lib.BUF_MINMAX), rf["minmax"])
+                img0, depth0 = p.project(P)
+                assert np.array_equal(depth0.view(np.uint32), ref["depth_bits"]) and np.array_equal(img0, ref["img"])
+                st = p.frame_stats()
+                assert st["errors"] == 0 and st["entries"] > 1_000_000
+            checked += 1
+        assert checked == 10
+    finally:
+        p.close()
