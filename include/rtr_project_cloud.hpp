@@ -15,12 +15,24 @@
 //                 caller-allocated CV_8UC3 / CV_32F of size W x H      (main.cpp:93-94)
 // Return codes as in project_cloud.cu:268-312: 1 on success, -1 when both outputs are null.
 // Unlike the reference (exit(1) on CUDA errors, project_cloud.cu:13-17) failures throw.
+//
+// computeFull (project_cloud.h:17-18, project_cloud.cu:437-493) needs libtorch: define RTR_WITH_TORCH
+// before including this header (and link libtorch); without it the class has the two projection
+// methods and tensor(), the device pointer computeFull hands to the U-Net.
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#ifdef RTR_WITH_TORCH
+#include <torch/script.h>
+
+#include <cstring>
+#include <filesystem>
+#endif
 
 #include "rtr.h"
 
@@ -45,6 +57,9 @@ public:
         check(nullptr, rtr_create(&ctx_, device));
         check(ctx_, rtr_set_option(ctx_, "auto_reorder", 1));  // one-off Morton sort: the grid's blocks are unordered inside
         check(ctx_, rtr_upload_points(ctx_, xyzw.data(), 16, rgba.data(), 4, xyzw.size() / 4));
+#ifdef RTR_WITH_TORCH
+        load_model(device);
+#endif
     }
     ProjectCloud(const ProjectCloud&) = delete;  // owns device buffers (the reference forgets this)
     ProjectCloud& operator=(const ProjectCloud&) = delete;
@@ -79,6 +94,50 @@ public:
     }
     template <class Calibration, class Extrinsics>
     int computeFilteredRGBD(const Calibration&, const Extrinsics&, std::nullptr_t, std::nullptr_t) { return -1; }
+#ifdef RTR_WITH_TORCH
+    // computeFull (project_cloud.cu:437-493): projection + prefilter, then the TorchScript model on the
+    // RESIDENT fp16 {1,5,H,W} tensor (torch::from_blob, no copy: :471), output[0] permuted to H x W x 3
+    // (:475) and converted like cv::Mat::convertTo(CV_8UC3, 255.0) (:480: scale, round half to even,
+    // saturate); depth <- the prefiltered depth buffer (:485).  Either output may be null; returns 1.
+    // The projector runs on HIP's default stream here, which is torch's current stream unless the caller
+    // changed it: kernels and the model are ordered without a host synchronisation.
+    template <class Calibration, class Extrinsics, class Image>
+    int computeFull(const Calibration& calibration, const Extrinsics& extrinsics, Image* color, Image* depth) {
+        if (!has_model_) throw std::runtime_error("rtr: No model file name given, computeFull will not work");  // :247
+        const int W = calibration.getWidth(), H = calibration.getHeight();
+        float P[16];
+        projection(calibration, extrinsics, P);
+        check(ctx_, rtr_set_resolution(ctx_, W, H));
+        check(ctx_, rtr_render(ctx_, P, 1));
+        torch::Tensor input = torch::from_blob(tensor(), {1, 5, H, W},
+                                               torch::TensorOptions().dtype(torch::kFloat16).device(torch::kCUDA, device_));
+        torch::NoGradGuard no_grad;
+        torch::Tensor output = model_.forward({input}).toTensor();
+        output = output[0].permute({1, 2, 0}).contiguous();
+        if (color != nullptr) {
+            torch::Tensor u8 = output.to(torch::kFloat32).mul(255.0).round().clamp(0.0, 255.0).to(torch::kUInt8).cpu();
+            std::memcpy(color->template ptr<uint8_t>(), u8.data_ptr<uint8_t>(), (size_t)W * H * 3);
+        }
+        if (depth != nullptr)
+            check(ctx_, rtr_download_buffer(ctx_, RTR_BUF_DEPTH, depth->template ptr<float>(), (size_t)W * H * 4));
+        return 1;
+    }
+    template <class Calibration, class Extrinsics, class Image>
+    int computeFull(const Calibration& c, const Extrinsics& e, Image* color, std::nullptr_t) {
+        return computeFull(c, e, color, static_cast<Image*>(nullptr));
+    }
+    template <class Calibration, class Extrinsics, class Image>
+    int computeFull(const Calibration& c, const Extrinsics& e, std::nullptr_t, Image* depth) {
+        return computeFull(c, e, static_cast<Image*>(nullptr), depth);
+    }
+    // a model object instead of a file under $HOME/.render_cache (tests, callers that build their own)
+    void set_model(torch::jit::Module m) {
+        model_ = std::move(m);
+        model_.to(torch::Device(torch::kCUDA, device_));
+        has_model_ = true;
+        check(ctx_, rtr_set_stream(ctx_, nullptr));
+    }
+#endif
     // computeFull (project_cloud.cu:437-493) = computeFilteredRGBD + the caller's U-Net on this
     // device pointer: torch::from_blob(tensor(), {1,5,H,W}, fp16, kCUDA)   (project_cloud.cu:471)
     void* tensor() const {
@@ -89,17 +148,36 @@ public:
     rtr_ctx* context() const { return ctx_; }
 
 private:
-    template <class Calibration, class Extrinsics, class Image>
-    int frame(const Calibration& calibration, const Extrinsics& extrinsics, Image* color, Image* depth, bool filtered) {
-        if (color == nullptr && depth == nullptr) return -1;  // project_cloud.cu:270-273
+    template <class Calibration, class Extrinsics>
+    static void projection(const Calibration& calibration, const Extrinsics& extrinsics, float P[16]) {
         double K[9], E[16];
         const auto Km = calibration.getIntrinsicsMatrix();
         for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 3; ++c) K[3 * r + c] = Km(r, c);
         for (int r = 0; r < 4; ++r)
             for (int c = 0; c < 4; ++c) E[4 * r + c] = extrinsics(r, c);
-        float P[16];
         rtr_compose_projection(K, E, P);  // project_cloud.cu:318
+    }
+#ifdef RTR_WITH_TORCH
+    void load_model(int device) {  // project_cloud.cu:225-250 (throws where the reference exits)
+        device_ = device;
+        if (model_filename_.empty()) return;  // "No model file name given, computeFull will not work."
+        const char* home = std::getenv("HOME");
+        const std::string path = (std::filesystem::path(home ? home : "") / ".render_cache" / model_filename_).string();
+        if (!std::filesystem::exists(path))
+            throw std::runtime_error("rtr: Model file does not exist: " + path + " (export a TorchScript model for this "
+                                     "camera resolution first)");
+        set_model(torch::jit::load(path));
+    }
+    torch::jit::Module model_;
+    bool has_model_ = false;
+    int device_ = 0;
+#endif
+    template <class Calibration, class Extrinsics, class Image>
+    int frame(const Calibration& calibration, const Extrinsics& extrinsics, Image* color, Image* depth, bool filtered) {
+        if (color == nullptr && depth == nullptr) return -1;  // project_cloud.cu:270-273
+        float P[16];
+        projection(calibration, extrinsics, P);
         check(ctx_, rtr_set_resolution(ctx_, calibration.getWidth(), calibration.getHeight()));  // :275-298
         uint8_t* c8 = color ? color->template ptr<uint8_t>() : nullptr;
         float* d32 = depth ? depth->template ptr<float>() : nullptr;

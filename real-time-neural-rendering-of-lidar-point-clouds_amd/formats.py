@@ -298,13 +298,24 @@ def compute_grid(xyz, colors, block_size=0.25):
     nb = (ext / f32(block_size)).astype(np.int32)  # int(...) truncation (cloudreader.cpp:39-41)
     with np.errstate(divide="ignore", invalid="ignore"):
         cell = np.floor(((xyz - bb_min).astype(f32) / ext).astype(f32) * nb.astype(f32)).astype(np.int64)
-    cell = np.clip(cell, 0, np.maximum(nb - 1, 0))  # the reference only warns when out of bounds (:54-55)
-    keys = (cell[:, 0] + cell[:, 1] * nb[0] + cell[:, 2] * nb[0] * nb[1]).astype(np.int64)
+    # Out-of-range cells (a point exactly on the rounded-out maximum, or a degenerate axis) only draw a
+    # warning in the reference (cloudreader.cpp:54-55); the key is computed from them as they are (:57-58)
+    oob = ((cell < 0) | (cell >= nb)).any(axis=1)
+    if oob.any():
+        import sys
+        first = cell[np.argmax(oob)]
+        print("out of bounds: %d, %d, %d  (%d points)" % (first[0], first[1], first[2], int(oob.sum())), file=sys.stderr)
+    keys = (cell[:, 0] + cell[:, 1] * nb[0] + cell[:, 2] * nb[0] * nb[1]).astype(np.int64)  # encodeKey (Octreegrid.h:48-50)
     order = np.argsort(keys, kind="stable")
     ukeys, first = np.unique(keys[order], return_index=True)
     offsets = np.concatenate([first, [len(keys)]]).astype(np.int64)
-    kz, rem = np.divmod(ukeys, nb[0] * nb[1])
-    ky, kx = np.divmod(rem, nb[0])
+    # decodeKey (Octreegrid.h:116-121): C++ int division and remainder truncate towards zero
+    nxy = int(nb[0]) * int(nb[1])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        kz = np.trunc(ukeys / nxy).astype(np.int64) if nxy else np.zeros_like(ukeys)
+        rem = ukeys - kz * nxy
+        ky = np.trunc(rem / int(nb[0])).astype(np.int64) if nb[0] else np.zeros_like(ukeys)
+        kx = np.fmod(rem, int(nb[0])).astype(np.int64) if nb[0] else np.zeros_like(ukeys)
     size = (ext / nb.astype(f32)).astype(f32)  # bbSize_* (cloudreader.cpp:67-76)
     kxyz = np.stack([kx, ky, kz], axis=1).astype(f32)
     blk_min = (bb_min + kxyz * size).astype(f32)

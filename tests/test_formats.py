@@ -96,6 +96,22 @@ def test_grid_and_pcd_oct(pkg, orc, tmp_path):
     assert np.fromfile(tmp_path / "pcd.oct", np.int32, 4).tolist() == [32, 16, 32, len(g)]
 
 
+def test_grid_keys_out_of_range_cells_like_the_reference(pkg, capsys):
+    """cloudreader.cpp:50-58: a point exactly on the rounded-out maximum lands in cell index numBlocks
+    (one past the grid); the reference prints "out of bounds" and keys it as computed -- no clipping."""
+    F = pkg.formats
+    xyz = np.array([[0.1, 0.1, 0.1], [1.0, 0.5, 0.5], [0.6, 0.6, 0.6]], np.float32)   # x = 1.0 = ceil(bbMax.x)
+    g = F.compute_grid(xyz, np.zeros((3, 3), np.uint8))
+    assert g.num_blocks == (4, 4, 4)
+    assert "out of bounds: 4, 2, 2" in capsys.readouterr().err
+    # encodeKey(4, 2, 2) = 4 + 2 * 4 + 2 * 16 = 44, which decodes (Octreegrid.h:116-121) to cell (0, 3, 2)
+    assert 44 in g.keys.tolist()
+    b = g.keys.tolist().index(44)
+    assert np.array_equal(g.xyz[g.offsets[b]:g.offsets[b + 1]], xyz[1:2])
+    assert np.allclose(g.bb_min[b], [0.0, 0.75, 0.5]) and np.allclose(g.bb_max[b], [0.25, 1.0, 0.75])
+    assert g.num_points() == 3  # nothing dropped, nothing moved
+
+
 def test_c1_plumbing_ply_to_frame_on_cpu(pkg, orc, tmp_path):
     """BASELINE config C1: 100k-point synthetic .ply -> 640x480 via the naive host-loop CPU
     projector: file -> grid -> flattened arrays -> oracle frame == frame of the original cloud."""
