@@ -76,7 +76,7 @@ struct StoreConsts {  // rarely needed, rarely changing: lives in the store's he
 //                  streams.  Records [0, nt): one per tile, at position perm[tile] (kItemSkip when the
 //                  tile is split); records [nt, nt + hdr[kHdrSplitItems]): the slices of split tiles
 //   perm[nt]       tile -> record position: tiles that held more than twice the mean entry count in
-//                  the PREVIOUS frame first (written by the tile kernel's mode-3 launch)
+//                  the PREVIOUS frame first (written by an extra workgroup of the tile launch)
 //   hdr[32]        kHdr* below; hdr[kHdrConsts ..] = StoreConsts
 //   ticket[2]      T1 workgroups that have finished
 //   pool_next[2]   (u64) entries of `dyn` handed out in this frame

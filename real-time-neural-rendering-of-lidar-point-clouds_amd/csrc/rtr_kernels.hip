@@ -353,6 +353,7 @@ constexpr int kTileH = 32;
 #endif
 constexpr int kTileThreads = RTR_TILE_THREADS;
 constexpr int kTileBatch = RTR_TILE_BATCH;    // entries in flight per thread in k_tile
+constexpr int kSplitGrid = 256; // workgroups of the mode-3 launch (they stride over the split tiles' slices)
 constexpr int kPer2 = kTileBatch / 2, kPer4 = kTileBatch / 4;  // registers per stream of a 2- / 4-stream tile
 constexpr int kMaxGroups = RTR_MAX_GROUPS;    // tile groups of a quad that get a wave-level claim; the rest claim per lane
 constexpr int kMaxSegs = 4 * kDirK;
@@ -666,8 +667,8 @@ __device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split) 
 
 // The launch order of the NEXT frame's tile kernel, from this frame's entry counts (consecutive frames
 // look alike): tiles with more than twice the mean entry count first, so the few heavy tiles that
-// bound T4 start at once instead of trailing the launch.  One workgroup of the mode-3 tile launch,
-// which has nothing else to do on ordinary frames -- off T1's critical path.
+// bound T4 start at once instead of trailing the launch.  One extra workgroup of the tile launch (modes 0
+// and 1), beside the ~2000 that are busy with tiles -- off every critical path.
 __device__ void next_frame_order(const TileStore &S) {
     __shared__ uint32_t s_w[8];
     const uint32_t *const tile_cnt = ts_tile_cnt(S);
@@ -1125,12 +1126,12 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
     // Records [0, ntiles): one tile each, for workgroups 0 .. ntiles - 1; records [ntiles, ...): the slices of
     // split tiles, dealt round-robin to the remaining workgroups (mode 3: to all of them) up to kItemEnd.
     const uint32_t nt = (uint32_t)g.ntiles;
-    if (MODE == 3 && blockIdx.x == gridDim.x - 1) {  // the extra workgroup of the mode-3 launch
+    if ((MODE == 0 || MODE == 1) && blockIdx.x == gridDim.x - 1) {  // one extra workgroup, beside ~2000 busy ones
         next_frame_order(S);
         return;
     }
     const bool tile_wg = MODE != 3 && blockIdx.x < nt;
-    const uint32_t split_step = MODE == 3 ? gridDim.x - 1u : gridDim.x - nt;
+    const uint32_t split_step = MODE == 3 ? gridDim.x : gridDim.x - nt - ((MODE == 0 || MODE == 1) ? 1u : 0u);
     // (a tile workgroup's record always exists; the others first learn how many slice records there are)
     const uint32_t n_split = tile_wg ? 0u : ts_hdr(S)[kHdrSplitItems];
     const uint32_t first = tile_wg ? blockIdx.x : nt + (MODE == 3 ? blockIdx.x : blockIdx.x - nt);
@@ -1385,7 +1386,7 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
             RTR_TSTAMP(9);
             __syncthreads();
             RTR_TSTAMP(10);
-            if (narrow) {
+            if (narrow && !(MODE == 0 && !split)) {  // (whole unsplit tiles check while they write out, below)
                 int over = 0;
                 for (int p = tid; p < tpix; p += T) over |= (s_acc64[p] >> 48) > 257ull;
                 if (__syncthreads_or(over)) {  // rare: some pixel blends more than 257 points
@@ -1457,7 +1458,8 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
             }
         }
         // write-out: rows of the tile are contiguous in memory
-        if (!split || (MODE == 3 && finish)) {
+        int over = 0;  // packed accumulators only: some pixel blended more than 257 points
+        auto write_out = [&]() {
             for (int p = tid; p < tpix; p += T) {
                 int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
                 bool inb = x < W && y < H;
@@ -1473,6 +1475,7 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
                 if (MODE != 1) {
                     uint32_t a0, a1, a2, c;
                     sums_of(p, a0, a1, a2, c);
+                    over |= (narrow && c > 257u) ? 1 : 0;
                     if (MODE == 2) {
                         if (inb) {
                             uint4 o = overwrite ? make_uint4(0u, 0u, 0u, 0u) : reinterpret_cast<uint4 *>(acc)[gp];
@@ -1486,10 +1489,25 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
                     }
                 }
             }
-        }
+        };
+        if (!split || (MODE == 3 && finish)) write_out();
         RTR_TSTAMP(5);
         if ((MODE == 0 && !split) || (MODE == 3 && finish)) {
-            __syncthreads();
+            // (the barrier the image rows need anyway also carries the verdict on the packed accumulators: an
+            // unsplit tile of a whole frame only ever OVERWRITES memory, so writing it out twice is harmless)
+            if (MODE == 0 && narrow) {
+                if (__syncthreads_or(over)) {  // rare: redo the tile with the wide layout
+                    narrow = false;
+                    for (int p = tid; p < 4 * tpix; p += T) s_acc[p] = 0;
+                    __syncthreads();
+                    accumulate(false);
+                    __syncthreads();
+                    write_out();
+                    __syncthreads();
+                }
+            } else {
+                __syncthreads();
+            }
             // image rows of the tile as dwords when the row segment is whole and 4-byte aligned
             const int row_dw = (3 * tw) >> 2;  // 24 or 48 dwords per tile row
             const bool fast = (tx0 + tw <= W) && ((W & 3) == 0);
@@ -1590,15 +1608,15 @@ void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, floa
     size_t lds = (mode == 1 ? tpix : 5 * tpix) * sizeof(uint32_t) + ((mode == 0 || mode == 3) ? 3 * tpix : 0);
     TilePyr none{};
     none.enable = 0;
-    const dim3 grid(g.ntiles + kHeavyExtra), block(kTileThreads);
+    const dim3 grid(g.ntiles + kHeavyExtra), grid1(g.ntiles + kHeavyExtra + 1), block(kTileThreads);
     if (mode == 0)
-        hipLaunchKernelGGL(k_tile<0>, grid, block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 1,
+        hipLaunchKernelGGL(k_tile<0>, grid1, block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 1,
                            pyr ? *pyr : none, nosl);
     else if (mode == 3)  // only the split tiles' slices: all of these workgroups leave at once on ordinary frames
-        hipLaunchKernelGGL(k_tile<3>, dim3(kHeavyExtra + 1), block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 1,
+        hipLaunchKernelGGL(k_tile<3>, dim3(kSplitGrid), block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 1,
                            pyr ? *pyr : none, nosl);
     else if (mode == 1)
-        hipLaunchKernelGGL(k_tile<1>, grid, block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 2, none, nosl);
+        hipLaunchKernelGGL(k_tile<1>, grid1, block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 2, none, nosl);
     else  // mode 2 always writes the accumulators; bit 1 of write_acc = overwrite; pyr: also emit the pyramid
         hipLaunchKernelGGL(k_tile<2>, grid, block, lds, s, S, g, W, H, window, depth, acc, img, 1 | (write_acc & 2),
                            pyr ? *pyr : none, depth_slices ? *depth_slices : nosl);

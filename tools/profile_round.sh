@@ -1,9 +1,16 @@
+# Round profile (GPU box): bench line, rocprofv3 kernel trace + the two PMC passes of the same command.
+# usage: bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>/
 set -e
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/p2
-cd $R && timeout -k 10 400 python bench.py > gpurun_out/p2/bench.json 2> gpurun_out/p2/bench.err
+TAG=${1:-p2}
+mkdir -p $R/gpurun_out/$TAG
+cd $R && timeout -k 10 300 python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/p2/trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra > $R/gpurun_out/p2/bench_prof.json 2>/dev/null
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p2/pmc_f -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-parity > /dev/null 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p2/pmc_w -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-parity > /dev/null 2>&1
-cat $R/gpurun_out/p2/bench.json
+ARGS="--steps 20 --warmup 3 --no-cpu-baseline --no-extra --no-parity"
+timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/trace -- python $R/bench.py $ARGS > $R/gpurun_out/$TAG/bench_prof.json 2>/dev/null
+timeout -k 10 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/$TAG/pmc_f -- python $R/bench.py $ARGS > /dev/null 2>&1
+timeout -k 10 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/$TAG/pmc_w -- python $R/bench.py $ARGS > /dev/null 2>&1
+# the incoherent scene as uploaded (auto_reorder off is what bench's uniform_box.as_uploaded leg uses)
+timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/trace_ubox -- python $R/bench.py $ARGS --scene uniform_box > $R/gpurun_out/$TAG/bench_prof_ubox.json 2>/dev/null
+python3 $R/tools/summarize_profile.py $R/gpurun_out/$TAG
+cat $R/gpurun_out/$TAG/bench.json | tail -c 600
