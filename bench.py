@@ -67,6 +67,8 @@ def parse():
                          "group, 2 frames in flight); the numbers are not a benchmark result")
     ap.add_argument("--time-all-kernels", action="store_true",
                     help="bracket every phase with HIP events (default: only the dominant streaming kernel)")
+    ap.add_argument("--overlap", type=int, default=0, choices=[0, 1],
+                    help="N=1: library option \"overlap\" (T1 of frame k+1 on a second stream beside the tail of frame k)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the separately reported legs (uniform_box, chunk culling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -190,6 +192,8 @@ def main():
                     pj.set_option("auto_reorder", auto_reorder)
                 pj.generate_synthetic(scene, SEEDS["C3"], self.lo, self.hi - self.lo, total)
                 pj.set_resolution(W, H)
+                if args.overlap and not multi:
+                    pj.set_option("overlap", 1)
                 lj = pkg.sharded.HipLocal(pj)
                 st = torch.cuda.Stream(device=local_rank) if (multi or depth_k > 1) else None
                 if st is not None:

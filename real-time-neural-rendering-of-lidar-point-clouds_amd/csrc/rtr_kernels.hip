@@ -353,6 +353,10 @@ constexpr int kTileH = 32;
 #endif
 constexpr int kTileThreads = RTR_TILE_THREADS;
 constexpr int kTileBatch = RTR_TILE_BATCH;    // entries in flight per thread in k_tile
+#ifndef RTR_T1_WAVES
+#define RTR_T1_WAVES 4  // the point kernel runs 4 waves per SIMD (1024 workgroups); capping it at 80 registers so that a
+#endif                  // tile workgroup of the previous frame fits beside it (option "overlap") spills in the hot loop:
+                        // +25 us alone, and the co-running tile kernel slows it further (measured: 0.333 vs 0.296 ms)
 constexpr int kSplitGrid = 256; // workgroups of the mode-3 launch (they stride over the split tiles' slices)
 constexpr int kPer2 = kTileBatch / 2, kPer4 = kTileBatch / 4;  // registers per stream of a 2- / 4-stream tile
 constexpr int kMaxGroups = RTR_MAX_GROUPS;    // tile groups of a quad that get a wave-level claim; the rest claim per lane
@@ -722,7 +726,7 @@ __device__ void next_frame_order(const TileStore &S) {
 // < 3e-7 x that magnitude, so no point the exact arithmetic would keep is ever skipped).
 // Only spatially coherent point orders have tight chunk boxes (rtr_reorder_points).
 template <bool CULL>
-__global__ __launch_bounds__(kBlock, 4) void k_project_bin(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
+__global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
                                                         const float4 *__restrict__ z4,
                                                         const uint4 *__restrict__ rgba4, uint32_t n4, Proj P, int W,
                                                         int H, TileStore S, const float *__restrict__ bounds,

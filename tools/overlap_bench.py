@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--settings", default="0:0,1:0,1:4,1:8,1:12,1:16")
     ap.add_argument("--filter", type=int, default=1)
     ap.add_argument("--cull", type=int, default=0)
+    ap.add_argument("--point-grid", type=int, default=0)
     args = ap.parse_args()
     pkg = entry.load_package()
     W, H, n = args.width, args.height, args.points
@@ -34,6 +35,8 @@ def main():
     if args.cull:
         p.reorder_points()
         p.set_option("cull", 1)
+    if args.point_grid:
+        p.set_option("point_grid", args.point_grid)
     poses = [pkg.orbit_projection(k, W, H) for k in range(args.frames + 10)]
     for setting in args.settings.split(","):
         ov, cus = (int(v) for v in setting.split(":"))
