@@ -373,14 +373,26 @@ def main():
                 info["used"] = "p2p"
         return dt_, timing_, info
 
-    dt, timing, exchange_info = run_exchange_forms(S, renderers, args.steps, args.warmup)
-    n_local = S.hi - S.lo
-
     def kernel_table(timing_):
         return {k: (ms / max(n, 1)) for k, (ms, n) in timing_.items() if n}
 
+    dt, timing, exchange_info = run_exchange_forms(S, renderers, args.steps, args.warmup)
+    n_local = S.hi - S.lo
+
     # Reported separately (never part of `value`), N = 1 only.
-    extra_cull, ubox = None, None
+    extra_cull, ubox, pipelined = None, None, None
+    if not multi and not args.no_extra and not args.overlap:
+        # (0) the same frames with library option "overlap": the point stream of frame k+1 is queued on a second
+        #     HIP stream and starts while the tile kernel / prefilter of frame k still run
+        proj.set_option("overlap", 1)
+        m = min(args.steps, 50)
+        dtp, tp = S.timed_run(renderers, m, min(args.warmup, 5))
+        proj.set_option("overlap", 0)
+        pipelined = {"what": "option overlap = 1: T1 of frame k+1 on a second stream beside the tail of frame k (two tile "
+                             "stores); same frames, bit-identical output.  Not the headline: beside the tail the point "
+                             "kernel's own launches stretch, so its roofline figure would no longer describe the kernel",
+                     "value": total * m / dtp / 1e6, "unit": "Mpoints/s", "ms_per_step": dtp / m * 1e3, "steps": m,
+                     "min_depth_avg_launch_ms": kernel_table(tp).get("min_depth")}
     if not multi and not args.no_extra:
         # (1) the same frames with exact per-chunk frustum culling on a Morton-sorted cloud: an algorithmic
         #     byte reduction, not a roofline claim
@@ -490,6 +502,7 @@ def main():
             "parity_vs_oracle": parity,
             "parity_vs_single_gpu": parity_single,
             "uniform_box": ubox,
+            "pipelined": pipelined,
             "with_chunk_culling": extra_cull,
         }
         if world > 1:

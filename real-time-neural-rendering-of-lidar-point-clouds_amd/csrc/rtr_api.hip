@@ -286,7 +286,10 @@ rtr::Proj make_proj(const float P[16]) {
     return p;
 }
 
-rtr::Cloud cloud_of(const rtr_ctx *c) { return rtr::Cloud{c->x, c->y, c->z, c->rgba, c->n, c->opt_grid}; }
+rtr::Cloud cloud_of(const rtr_ctx *c) {
+    // (a chunk of 256 points as large as a quarter of the cloud: consecutive points are unrelated)
+    return rtr::Cloud{c->x, c->y, c->z, c->rgba, c->n, c->opt_grid, (!c->reordered && c->order_ratio > 0.25f) ? 1 : 0};
+}
 
 struct Timed {  // brackets one phase with hipEvents on the stream it is launched on
     rtr_ctx *c; int k; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
@@ -664,16 +667,16 @@ int rtr_synchronize(rtr_ctx *c) {
 static int auto_reorder(rtr_ctx *c) {
     c->reordered = false;
     c->order_ratio = 0.f;
-    if (c->opt_auto_reorder == 0 || c->n < 2) return RTR_OK;
+    if (c->n < 2) return RTR_OK;
     bool want = c->opt_auto_reorder == 1;
-    if (!want && c->n >= (1u << 16)) {  // (tiny clouds render in microseconds whatever their order)
-        float ratio = 0.f;
+    if (c->n >= (1u << 16)) {  // (tiny clouds render in microseconds whatever their order)
+        float ratio = 0.f;     // measured under every policy: the point kernel has a form for incoherent clouds
         if (rtr::order_quality(c->stream, c->bounds, c->n, &ratio) != 0) {
             (void)hipGetLastError();
             return RTR_OK;
         }
         c->order_ratio = ratio;
-        want = ratio > 2.0f * cbrtf(256.0f / (float)c->n);
+        if (c->opt_auto_reorder == 2) want = ratio > 2.0f * cbrtf(256.0f / (float)c->n);
     }
     if (!want) return RTR_OK;
     if (rtr_reorder_points(c) != RTR_OK) (void)hipGetLastError();

@@ -18,6 +18,7 @@ struct Cloud {
     const uint32_t *rgba;    // packed c0 | c1<<8 | c2<<16 | 255<<24
     uint64_t n;              // real point count
     int grid;                // workgroups of the grid-stride point kernels
+    int incoherent;          // consecutive points are unrelated (measured at upload): no wave-level claim groups
 };
 
 struct FilterLevels {

@@ -725,7 +725,10 @@ __device__ void next_frame_order(const TileStore &S) {
 // 1e-4 x the magnitude of the terms involved (the fp32 evaluation of r.x, r.y, r.z errs by
 // < 3e-7 x that magnitude, so no point the exact arithmetic would keep is ever skipped).
 // Only spatially coherent point orders have tight chunk boxes (rtr_reorder_points).
-template <bool CULL>
+// GROUPS = false: a cloud whose consecutive points are unrelated (measured at upload: its 256-point chunks
+// span a quarter of the cloud or more) and that the caller asked not to sort -- every quad's points fall
+// into as many tiles as it has points, so the grouping rounds are skipped and every point claims per lane.
+template <bool CULL, bool GROUPS>
 __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
                                                         const float4 *__restrict__ z4,
                                                         const uint4 *__restrict__ rgba4, uint32_t n4, Proj P, int W,
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
 #pragma clang diagnostic pop
         int ng = 0;
 #pragma unroll
-        for (int it = 0; it < kMaxGroups; ++it) {
+        for (int it = 0; it < (GROUPS ? kMaxGroups : 0); ++it) {
             const int kk = pm[0] ? 0 : (pm[1] ? 1 : (pm[2] ? 2 : (pm[3] ? 3 : -1)));
             if (kk < 0) continue;  // wave-uniform
             const unsigned long long pk = kk == 0 ? pm[0] : (kk == 1 ? pm[1] : (kk == 2 ? pm[2] : pm[3]));
@@ -1549,11 +1552,15 @@ void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int
         return;
     }
     if (bounds)
-        hipLaunchKernelGGL(k_project_bin<true>, dim3(point_grid(n4, c.grid)), dim3(kBlock), 0, s, (const float4 *)c.x,
+        hipLaunchKernelGGL((k_project_bin<true, true>), dim3(point_grid(n4, c.grid)), dim3(kBlock), 0, s, (const float4 *)c.x,
+                           (const float4 *)c.y, (const float4 *)c.z, (const uint4 *)c.rgba, (uint32_t)n4, P, W, H, S, bounds,
+                           clear_split, (uint32_t)phases, xp);
+    else if (c.incoherent)
+        hipLaunchKernelGGL((k_project_bin<false, false>), dim3(point_grid(n4, c.grid)), dim3(kBlock), 0, s, (const float4 *)c.x,
                            (const float4 *)c.y, (const float4 *)c.z, (const uint4 *)c.rgba, (uint32_t)n4, P, W, H, S, bounds,
                            clear_split, (uint32_t)phases, xp);
     else
-        hipLaunchKernelGGL(k_project_bin<false>, dim3(point_grid(n4, c.grid)), dim3(kBlock), 0, s, (const float4 *)c.x,
+        hipLaunchKernelGGL((k_project_bin<false, true>), dim3(point_grid(n4, c.grid)), dim3(kBlock), 0, s, (const float4 *)c.x,
                            (const float4 *)c.y, (const float4 *)c.z, (const uint4 *)c.rgba, (uint32_t)n4, P, W, H, S, bounds,
                            clear_split, (uint32_t)phases, xp);
 }

@@ -157,7 +157,7 @@ int order_quality(hipStream_t s, const float *bounds, uint64_t n, float *ratio) 
     if (e != hipSuccess) return (int)e;
     e = hipMemcpyAsync(d, &init, sizeof init, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
-        const unsigned grid = (unsigned)((nchunks + 255) / 256 < 1024 ? (nchunks + 255) / 256 : 1024);
+        const unsigned grid = (unsigned)((nchunks + 255) / 256 < 128 ? (nchunks + 255) / 256 : 128);  // (few waves: eight same-address atomics each)
         hipLaunchKernelGGL(k_order_quality, dim3(grid), dim3(256), 0, s, bounds, nchunks, &d->sum, &d->finite, d->bb);
         e = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, s);
     }
