@@ -293,7 +293,9 @@ rtr::Cloud cloud_of(const rtr_ctx *c) {
 
 struct Timed {  // brackets one phase with hipEvents on the stream it is launched on
     rtr_ctx *c; int k; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
-    Timed(rtr_ctx *c_, int k_, hipStream_t s_ = nullptr) : c(c_), k(k_), s(s_ ? s_ : c_->stream) {
+    bool in_dispatch;  // the launch itself carries the two events (hipExtLaunchKernelGGL): nothing to record here
+    Timed(rtr_ctx *c_, int k_, hipStream_t s_ = nullptr, bool in_dispatch_ = false)
+        : c(c_), k(k_), s(s_ ? s_ : c_->stream), in_dispatch(in_dispatch_) {
         if (!c->timing) return;
         if (c->timing >= 2 && k != RTR_K_MIN_DEPTH && k != RTR_K_ACCUMULATE) return;
         if (c->timing == 3 && (c->timing_tick++ & 3u) != 0u) return;  // a bracket costs ~8 us of stream time
@@ -302,11 +304,11 @@ struct Timed {  // brackets one phase with hipEvents on the stream it is launche
         } else {
             a = c->pool.back().first; b = c->pool.back().second; c->pool.pop_back();
         }
-        (void)hipEventRecord(a, s);
+        if (!in_dispatch) (void)hipEventRecord(a, s);
     }
     ~Timed() {
         if (!a) return;
-        (void)hipEventRecord(b, s);
+        if (!in_dispatch) (void)hipEventRecord(b, s);
         c->pending.push_back({a, b, k});
     }
 };
@@ -870,9 +872,9 @@ static int bin_points(rtr_ctx *c, const float P[16], bool overlapped, bool clear
         t.seq = 1u;
     }
     {
-        Timed tm(c, RTR_K_MIN_DEPTH, s1);
+        Timed tm(c, RTR_K_MIN_DEPTH, s1, true);
         rtr::launch_project_bin(s1, cloud_of(c), make_proj(P), c->W, c->H, t, c->opt_cull ? c->bounds : nullptr,
-                                clear_split ? 1 : 0, c->opt_phases, c->opt_xp);
+                                clear_split ? 1 : 0, c->opt_phases, c->opt_xp, tm.a, tm.b);
         c->p2p.occ_from_scan = c->p2p.open;
     }
     if (overlapped) {

@@ -134,7 +134,8 @@ int storage_tile_count(int W, int H);  // 32x16 storage tiles
 // the occupancy bitmap of the peer-to-peer exchange are named by StoreConsts in the store's header).
 // bounds != NULL enables per-chunk frustum culling (see k_project_bin)
 void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const TileStore &S,
-                        const float *bounds, int clear_split, int phases, int xp = 0);
+                        const float *bounds, int clear_split, int phases, int xp = 0, hipEvent_t ev_start = nullptr,
+                        hipEvent_t ev_stop = nullptr);  // ev_*: time stamps taken by the dispatch itself (timing on)
 void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds);  // 6 floats per 256 points
 int reorder_morton(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, uint64_t n);  // rtr_reorder.hip
 // mean diagonal of the 256-point chunk boxes / diagonal of the cloud's box, from launch_chunk_bounds' output

@@ -7,6 +7,7 @@
 // a scatter, so the work goes into coalescing, atomic traffic and launch count.
 #include "rtr_kernels.h"
 
+#include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 
 #include <type_traits>
@@ -1545,24 +1546,26 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
 }
 
 void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const TileStore &S,
-                        const float *bounds, int clear_split, int phases, int xp) {
+                        const float *bounds, int clear_split, int phases, int xp, hipEvent_t ev_start, hipEvent_t ev_stop) {
     uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) {
-        hipLaunchKernelGGL(k_bin_empty, dim3(1), dim3(kBlock), 0, s, W, H, S, clear_split);
+        hipExtLaunchKernelGGL(k_bin_empty, dim3(1), dim3(kBlock), 0, s, ev_start, ev_stop, 0, W, H, S, clear_split);
         return;
     }
+    // (hipExtLaunchKernelGGL with null events is a plain launch; with events the dispatch packet itself carries
+    // the start / stop time stamps: no extra packets around the kernel, unlike hipEventRecord pairs)
+    const dim3 grid(point_grid(n4, c.grid)), block(kBlock);
+    const float4 *x = (const float4 *)c.x, *y = (const float4 *)c.y, *z = (const float4 *)c.z;
+    const uint4 *col = (const uint4 *)c.rgba;
     if (bounds)
-        hipLaunchKernelGGL((k_project_bin<true, true>), dim3(point_grid(n4, c.grid)), dim3(kBlock), 0, s, (const float4 *)c.x,
-                           (const float4 *)c.y, (const float4 *)c.z, (const uint4 *)c.rgba, (uint32_t)n4, P, W, H, S, bounds,
-                           clear_split, (uint32_t)phases, xp);
+        hipExtLaunchKernelGGL((k_project_bin<true, true>), grid, block, 0, s, ev_start, ev_stop, 0, x, y, z, col, (uint32_t)n4, P,
+                              W, H, S, bounds, clear_split, (uint32_t)phases, xp);
     else if (c.incoherent)
-        hipLaunchKernelGGL((k_project_bin<false, false>), dim3(point_grid(n4, c.grid)), dim3(kBlock), 0, s, (const float4 *)c.x,
-                           (const float4 *)c.y, (const float4 *)c.z, (const uint4 *)c.rgba, (uint32_t)n4, P, W, H, S, bounds,
-                           clear_split, (uint32_t)phases, xp);
+        hipExtLaunchKernelGGL((k_project_bin<false, false>), grid, block, 0, s, ev_start, ev_stop, 0, x, y, z, col, (uint32_t)n4,
+                              P, W, H, S, bounds, clear_split, (uint32_t)phases, xp);
     else
-        hipLaunchKernelGGL((k_project_bin<false, true>), dim3(point_grid(n4, c.grid)), dim3(kBlock), 0, s, (const float4 *)c.x,
-                           (const float4 *)c.y, (const float4 *)c.z, (const uint4 *)c.rgba, (uint32_t)n4, P, W, H, S, bounds,
-                           clear_split, (uint32_t)phases, xp);
+        hipExtLaunchKernelGGL((k_project_bin<false, true>), grid, block, 0, s, ev_start, ev_stop, 0, x, y, z, col, (uint32_t)n4,
+                              P, W, H, S, bounds, clear_split, (uint32_t)phases, xp);
 }
 
 // bounding box of every 256-point chunk (the unit one wave of T1 handles per iteration):
