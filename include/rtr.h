@@ -87,6 +87,15 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *  "cull": 1 = skip 256-point chunks whose bounding box is provably outside the frustum
  *          (exact: same frame; an algorithmic byte reduction, off by default and reported
  *          separately from the roofline figure; needs a spatially coherent point order).
+ *  "pack": the tile-binned point kernel reads the coordinates from a LOSSLESS packed form, built once after
+ *          every upload / generation / sort (and at once for the resident cloud when the option is set): per
+ *          256-point chunk and axis the fp32 bit patterns are base + delta with 0..4 delta bytes, i.e. 6-9
+ *          B/pt instead of 12 for spatially ordered clouds (neighbours share sign, exponent and leading
+ *          mantissa bits); any bit pattern round-trips (NaNs, -0, mixed signs take 4 bytes).  1 (default):
+ *          used when it saves at least 1/8 of the stream; 0: never; 2: always, and the packed form is
+ *          decoded and compared with the SoA arrays once (an error if a single point differs).  The SoA
+ *          arrays stay resident (+6-9 B/pt).  rtr_get_option: "packed" (1: in use),
+ *          "packed_millibytes_per_point" (coordinate stream incl. headers, 12000 = raw).
  *  "keep_accum": 1 = the whole-frame calls also write RTR_BUF_ACCUM (default 0; the phase
  *          calls always do).
  *  "overlap": 1 = rtr_render queues the point stream (T1) of a frame on a second, internal
@@ -95,7 +104,8 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          on MI355X the gain is 0-3 % ("Overlap").  "tail_cus" = t (0..31, set
  *          before "overlap") additionally gives the two streams disjoint CU masks, t CUs of every
  *          XCD for the tail.
- *  "point_grid": workgroups of the grid-stride point kernels (default 1024 = 4 per CU).
+ *  "point_grid": workgroups of the grid-stride point kernels (default 1024 = 4 per CU; at the default the
+ *          tile-binned point kernel takes 1280 when it reads packed coordinates).
  *  "phases": the point kernel's workgroups are cut into this many groups that start at different
  *          places of the cloud (default 1: measured best); "fill_shift": the per-tile stream counters
  *          lie 4 << value bytes apart (default 2; packed counters share memory channels and queue up).
@@ -105,8 +115,9 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          timing attribution -- frames are WRONG while it is non-zero; the shipped library rejects it.
  *  "probe_variant": measurement aid of tools/probe_variants.py (selects the rtr_stream_probe kernel). */
 int rtr_set_option(rtr_ctx *ctx, const char *key, int value);
-/* Reads an option back; also "reordered" (1: the resident cloud was sorted by the library) and
- * "order_ratio_ppm" (mean chunk-box diagonal / cloud diagonal as uploaded, in millionths). */
+/* Reads an option back; also "reordered" (1: the resident cloud was sorted by the library),
+ * "order_ratio_ppm" (mean chunk-box diagonal / cloud diagonal as uploaded, in millionths), "packed" and
+ * "packed_millibytes_per_point" (see "pack"). */
 int rtr_get_option(rtr_ctx *ctx, const char *key, int *value);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's
  * own non-blocking stream; NULL means HIP's default stream.  rtr_reset_stream returns to the

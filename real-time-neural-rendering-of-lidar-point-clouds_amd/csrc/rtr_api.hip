@@ -30,6 +30,10 @@ struct rtr_ctx {
     uint32_t *rgba = nullptr;
     float *bounds = nullptr;    // bounding box per 256-point chunk (frustum culling option)
     uint64_t n = 0, cap = 0;
+    uint4 *pk_hdr = nullptr;        // rtr::PackedXyz of the resident cloud (option "pack"); null: not in use
+    uint32_t *pk_planes = nullptr;
+    uint64_t pk_bytes = 0;          // headers + planes
+    int opt_pack = 1;               // 0 never, 1 when it saves >= 1/8 of the coordinate stream, 2 always + verified after packing
 
     // frame buffers
     int W = 0, H = 0;
@@ -204,8 +208,14 @@ void free_lists(rtr_ctx *c) {  // the dynamic extent pools (sized by the point c
     c->list_valid = false;
 }
 
+void free_pack(rtr_ctx *c) {
+    dfree(c->pk_hdr); dfree(c->pk_planes);
+    c->pk_bytes = 0;
+}
+
 void free_cloud(rtr_ctx *c) {
     dfree(c->x); dfree(c->y); dfree(c->z); dfree(c->rgba); dfree(c->bounds);
+    free_pack(c);
     free_lists(c);
     c->n = c->cap = 0;
 }
@@ -288,7 +298,8 @@ rtr::Proj make_proj(const float P[16]) {
 
 rtr::Cloud cloud_of(const rtr_ctx *c) {
     // (a chunk of 256 points as large as a quarter of the cloud: consecutive points are unrelated)
-    return rtr::Cloud{c->x, c->y, c->z, c->rgba, c->n, c->opt_grid, (!c->reordered && c->order_ratio > 0.25f) ? 1 : 0};
+    return rtr::Cloud{c->x, c->y, c->z, c->rgba, c->n, c->opt_grid, (!c->reordered && c->order_ratio > 0.25f) ? 1 : 0,
+                      rtr::PackedXyz{c->pk_hdr, c->pk_planes}};
 }
 
 struct Timed {  // brackets one phase with hipEvents on the stream it is launched on
@@ -521,6 +532,8 @@ static int set_overlap(rtr_ctx *c, bool on) {
     return RTR_OK;
 }
 
+static int pack_cloud(rtr_ctx *c);
+
 int rtr_set_option(rtr_ctx *c, const char *key, int value) {
     if (!c) return RTR_ERR_INVALID;
     NEED(c, key != nullptr, "key is NULL");
@@ -582,6 +595,13 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
         c->opt_cull = value != 0;
         return RTR_OK;
     }
+    if (!strcmp(key, "pack")) {  // applies to the resident cloud at once, and to every later one
+        NEED(c, value >= 0 && value <= 2, "pack must be 0 (never), 1 (when it pays) or 2 (always, verified)");
+        c->opt_pack = value;
+        DevGuard g(c->device);
+        HIP_TRY(c, sync_streams(c));
+        return pack_cloud(c);
+    }
     if (!strcmp(key, "probe_variant")) {
         c->opt_probe = value;
         return RTR_OK;
@@ -608,6 +628,10 @@ int rtr_get_option(rtr_ctx *c, const char *key, int *value) {
     else if (!strcmp(key, "reordered")) *value = c->reordered ? 1 : 0;  // the resident cloud was sorted by the library
     else if (!strcmp(key, "order_ratio_ppm")) *value = (int)(c->order_ratio * 1e6f);  // chunk / cloud diagonal as uploaded
     else if (!strcmp(key, "cull")) *value = c->opt_cull;
+    else if (!strcmp(key, "pack")) *value = c->opt_pack;
+    else if (!strcmp(key, "packed")) *value = c->pk_hdr ? 1 : 0;  // the point kernel reads the packed coordinates
+    else if (!strcmp(key, "packed_millibytes_per_point"))         // its coordinate stream, headers included (12000 = raw)
+        *value = c->pk_hdr && c->n ? (int)(c->pk_bytes * 1000 / c->n) : 12000;
     else if (!strcmp(key, "keep_accum")) *value = c->opt_keep_accum;
     else if (!strcmp(key, "split_threshold")) *value = c->opt_heavy;
     else if (!strcmp(key, "split_slice")) *value = c->opt_slice;
@@ -666,6 +690,57 @@ int rtr_synchronize(rtr_ctx *c) {
 // on the point order; rtr_download_points returns the resident (possibly sorted) order.
 // Best effort: the sort works on scratch copies and only writes the cloud back at the very end, so a
 // cloud too large for the scratch simply stays in the order it was uploaded in.
+// Option "pack" (after every upload / generation / reorder): the tile-binned point kernel reads the
+// coordinates from the lossless PackedXyz form when that is at least 1/8 smaller than the 12 B/pt SoA
+// stream (spatially ordered clouds: 6-9 B/pt; a hash-ordered one stays raw).  The SoA arrays stay resident
+// -- the atomic form, the phase calls with another matrix, rtr_download_points and the sort use them.
+// Best effort: without memory for it the cloud simply stays unpacked.
+static int pack_cloud(rtr_ctx *c) {
+    free_pack(c);
+    if (c->opt_pack == 0 || c->n == 0) return RTR_OK;
+    const uint64_t n4 = (c->n + 3) / 4, nchunks = (n4 + 63) / 64;
+    struct Scratch {  // freed on every exit path
+        void *p = nullptr;
+        ~Scratch() { if (p) (void)hipFree(p); }
+    } cnt, tot;
+    uint4 *hdr = nullptr;
+    uint32_t *planes = nullptr;
+    auto give_up = [&]() {
+        (void)hipGetLastError();
+        if (hdr) (void)hipFree(hdr);
+        if (planes) (void)hipFree(planes);
+        return RTR_OK;
+    };
+    if (hipMalloc((void **)&hdr, nchunks * 2 * sizeof(uint4)) != hipSuccess) return give_up();
+    if (hipMalloc(&cnt.p, nchunks * sizeof(uint32_t)) != hipSuccess) return give_up();
+    if (hipMalloc(&tot.p, 2 * sizeof(uint64_t)) != hipSuccess) return give_up();
+    if (hipMemsetAsync(tot.p, 0, 2 * sizeof(uint64_t), c->stream) != hipSuccess) return give_up();
+    const rtr::Cloud cl = cloud_of(c);
+    rtr::pack_measure(c->stream, cl, hdr, (uint32_t *)cnt.p, (uint64_t *)tot.p);
+    uint64_t host[2] = {0, 0};
+    if (hipMemcpyAsync(host, tot.p, sizeof host, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return give_up();
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return give_up();
+    const uint64_t bytes = host[0] * 256 + nchunks * 32;
+    if (c->opt_pack == 1 && bytes * 8 > n4 * 48 * 7) return give_up();  // saves less than 1/8 of the 12 B/pt stream
+    // (one spare plane: the point kernel reads a chunk's first plane even when the chunk has none)
+    if (hipMalloc((void **)&planes, (host[0] + 1) * 256) != hipSuccess) return give_up();
+    if (hipMemsetAsync(planes + host[0] * 64, 0, 256, c->stream) != hipSuccess) return give_up();
+    rtr::pack_write(c->stream, cl, hdr, planes);
+    if (c->opt_pack == 2) {
+        rtr::pack_verify(c->stream, cl, hdr, planes, (uint64_t *)tot.p + 1);
+        if (hipMemcpyAsync(host, tot.p, sizeof host, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return give_up();
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return give_up();
+    if (c->opt_pack == 2 && host[1] != 0) {
+        (void)give_up();
+        return fail(c, RTR_ERR_HIP, "pack: %llu points decode to other coordinates", (unsigned long long)host[1]);
+    }
+    c->pk_hdr = hdr;
+    c->pk_planes = planes;
+    c->pk_bytes = bytes;
+    return RTR_OK;
+}
+
 static int auto_reorder(rtr_ctx *c) {
     c->reordered = false;
     c->order_ratio = 0.f;
@@ -718,7 +793,9 @@ int rtr_upload_points(rtr_ctx *c, const float *xyz, size_t xs, const uint8_t *rg
     rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
     HIP_TRY(c, sync_streams(c));
     if (int rc2 = launch_check(c, "aos_to_soa")) return rc2;
-    return auto_reorder(c);
+    free_pack(c);
+    if (int rc2 = auto_reorder(c)) return rc2;
+    return c->pk_hdr ? RTR_OK : pack_cloud(c);  // (a sort has packed already)
 }
 
 int rtr_generate_synthetic(rtr_ctx *c, int scene, uint64_t seed, uint64_t first, uint64_t count, uint64_t total) {
@@ -736,7 +813,9 @@ int rtr_generate_synthetic(rtr_ctx *c, int scene, uint64_t seed, uint64_t first,
     rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
     HIP_TRY(c, sync_streams(c));
     if (int rc2 = launch_check(c, "generate")) return rc2;
-    return auto_reorder(c);
+    free_pack(c);
+    if (int rc2 = auto_reorder(c)) return rc2;
+    return c->pk_hdr ? RTR_OK : pack_cloud(c);
 }
 
 int rtr_reorder_points(rtr_ctx *c) {
@@ -747,9 +826,11 @@ int rtr_reorder_points(rtr_ctx *c) {
     int e = rtr::reorder_morton(c->stream, c->x, c->y, c->z, c->rgba, c->n);
     if (e != 0) return fail(c, RTR_ERR_HIP, "reorder failed: %s", hipGetErrorString((hipError_t)e));
     c->reordered = true;
+    free_pack(c);
     rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
     HIP_TRY(c, sync_streams(c));
-    return launch_check(c, "reorder");
+    if (int rc = launch_check(c, "reorder")) return rc;
+    return pack_cloud(c);
 }
 
 int rtr_num_points(const rtr_ctx *c, uint64_t *n) {

@@ -13,12 +13,28 @@ struct Proj {
     float m[12];
 };
 
+// Lossless resident form of the coordinates for the tile-binned point kernel (option "pack").  A chunk =
+// 256 consecutive points = what one wave handles per iteration (lane l: points 4 l .. 4 l + 3).  Per
+// chunk and axis the fp32 BIT PATTERNS are stored as base + delta, base = the chunk's smallest pattern
+// (unsigned), delta in w = 0..4 bytes (0: the axis is constant in the chunk; 4: anything -- NaNs, mixed
+// signs).  Byte j of the four deltas of a lane forms one dword of "plane" j, and a plane is the 64
+// dwords of the wave (256 contiguous bytes): a chunk is wx + wy + wz planes, x planes first.
+// hdr[2 c] = {base x, base y, base z, wx | wy << 3 | wz << 6}, hdr[2 c + 1] = {first plane (lo, hi), 0, 0}.
+// The plane buffer ends with one spare plane (a chunk's first plane is readable even if it has none).
+// Spatially ordered clouds need 2-3 bytes per coordinate (neighbours share sign, exponent and leading
+// mantissa bits): 6-9 B/pt instead of 12, decoded with 12 byte-permutes and 4 adds per axis.
+struct PackedXyz {
+    const uint4 *hdr;        // null: not packed
+    const uint32_t *planes;
+};
+
 struct Cloud {
     const float *x, *y, *z;  // SoA, padded to a multiple of 4 points with NaN
     const uint32_t *rgba;    // packed c0 | c1<<8 | c2<<16 | 255<<24
     uint64_t n;              // real point count
     int grid;                // workgroups of the grid-stride point kernels
     int incoherent;          // consecutive points are unrelated (measured at upload): no wave-level claim groups
+    PackedXyz pk;            // the same coordinates, packed (only read by launch_project_bin)
 };
 
 struct FilterLevels {
@@ -137,6 +153,12 @@ void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int
                         const float *bounds, int clear_split, int phases, int xp = 0, hipEvent_t ev_start = nullptr,
                         hipEvent_t ev_stop = nullptr);  // ev_*: time stamps taken by the dispatch itself (timing on)
 void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds);  // 6 floats per 256 points
+// packing (see PackedXyz): pack_measure fills hdr[2 nchunks] (bases, widths, plane offsets by an exclusive
+// scan) and *total_planes (device); pack_write fills the planes; pack_verify counts the points whose decoded
+// coordinates differ from the raw ones (must be 0) into *mismatches (device).  nchunks = ceil(ceil(n / 4) / 64).
+void pack_measure(hipStream_t s, const Cloud &c, uint4 *hdr, uint32_t *chunk_planes, uint64_t *total_planes);
+void pack_write(hipStream_t s, const Cloud &c, const uint4 *hdr, uint32_t *planes);
+void pack_verify(hipStream_t s, const Cloud &c, const uint4 *hdr, const uint32_t *planes, uint64_t *mismatches);
 int reorder_morton(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, uint64_t n);  // rtr_reorder.hip
 // mean diagonal of the 256-point chunk boxes / diagonal of the cloud's box, from launch_chunk_bounds' output
 int order_quality(hipStream_t s, const float *bounds, uint64_t n, float *ratio);

@@ -699,6 +699,44 @@ __device__ void next_frame_order(const TileStore &S) {
         }
 }
 
+// PackedXyz helpers ---------------------------------------------------------------
+// 4 x 4 byte transpose: out[j] = (byte j of in[0], byte j of in[1], byte j of in[2], byte j of in[3]).
+// Deltas of a lane's four points <-> its dwords in planes 0..3; its own inverse.  v_perm_b32(S0, S1, sel):
+// selector 0-3 picks a byte of S1 (the second argument), 4-7 a byte of S0.
+__device__ __forceinline__ void transpose_bytes(const uint32_t in[4], uint32_t out[4]) {
+    const uint32_t t0 = __builtin_amdgcn_perm(in[1], in[0], 0x05010400u), t1 = __builtin_amdgcn_perm(in[1], in[0], 0x07030602u);
+    const uint32_t t2 = __builtin_amdgcn_perm(in[3], in[2], 0x05010400u), t3 = __builtin_amdgcn_perm(in[3], in[2], 0x07030602u);
+    out[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+    out[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+    out[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+    out[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+}
+__device__ __forceinline__ uint32_t ld_stream_u32(const uint32_t *p) { return __builtin_nontemporal_load(p); }
+// the (up to) twelve plane dwords of lane `lane` of the chunk with header words h0, h1; the branches are
+// wave-uniform.  (Always issuing twelve loads -- absent planes re-reading a line the wave fetches anyway, or a
+// shared block of zeros -- would let the compiler count the loads and keep two chunks in flight, but the extra
+// load instructions cost more than that gains: 208 and 309 us against 161.)
+__device__ __forceinline__ void load_planes(const uint32_t *__restrict__ planes, const uint4 &h0, const uint4 &h1, int lane,
+                                            uint32_t d[12]) {
+    const uint32_t *p = planes + (((((uint64_t)h1.y) << 32) | (uint64_t)h1.x) << 6) + lane;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const uint32_t w = (h0.w >> (3 * a)) & 7u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            d[4 * a + j] = 0u;
+            if (w > (uint32_t)j) d[4 * a + j] = ld_stream_u32(p + 64 * j);
+        }
+        p += 64u * w;
+    }
+}
+__device__ __forceinline__ float4 unpack_axis(const uint32_t planes[4], uint32_t base) {  // absent planes are 0
+    uint32_t e[4];
+    transpose_bytes(planes, e);
+    return make_float4(__uint_as_float(base + e[0]), __uint_as_float(base + e[1]), __uint_as_float(base + e[2]),
+                       __uint_as_float(base + e[3]));
+}
+
 // T1 ------------------------------------------------------------------------------
 // VALU matters here (a loads-only probe streams at 6.9 TB/s, with the projection arithmetic
 // at 6.0), so the quad is culled in three wave-uniform steps before the expensive part:
@@ -729,13 +767,18 @@ __device__ void next_frame_order(const TileStore &S) {
 // GROUPS = false: a cloud whose consecutive points are unrelated (measured at upload: its 256-point chunks
 // span a quarter of the cloud or more) and that the caller asked not to sort -- every quad's points fall
 // into as many tiles as it has points, so the grouping rounds are skipped and every point claims per lane.
-template <bool CULL, bool GROUPS>
+// PACKED: the coordinates come from the PackedXyz form (x4 = its headers, y4 = its planes, z4 unused): 6-9
+// bytes per point instead of 12 for spatially ordered clouds.  A chunk's header is requested one iteration
+// before its planes, the planes one iteration before they are decoded.
+template <bool CULL, bool GROUPS, bool PACKED>
 __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
                                                         const float4 *__restrict__ z4,
                                                         const uint4 *__restrict__ rgba4, uint32_t n4, Proj P, int W,
                                                         int H, TileStore S, const float *__restrict__ bounds,
                                                         int clear_split, uint32_t cblock, int xp) {
     (void)xp;
+    const uint4 *const pk_hdr = reinterpret_cast<const uint4 *>(x4);
+    const uint32_t *const pk_planes = reinterpret_cast<const uint32_t *>(y4);
     const float fW = (float)W, fH = (float)H;
     const float hiW = f_add(fW, 0.25f), hiH = f_add(fH, 0.25f);
     const int lane = threadIdx.x & 63;
@@ -855,7 +898,7 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
                     grp[k] = it;
                     rank[k] = lower++;
                 }
-            if (lane == it && !RTR_XP(2)) claim[it] = atomicAdd(fill + ((size_t)lead << S.fill_shift), total);
+            if (lane == it) claim[it] = atomicAdd(fill + ((size_t)lead << S.fill_shift), total);
             ng = it + 1;
             covered += total;
             if (it == 3 && covered <= 8u) {            // four tiles, at most two points each: an incoherent cloud (or a
@@ -918,7 +961,45 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
         }
     };
 
-    if (!CULL) {
+    if (!CULL && PACKED) {
+        // the same pipeline as below on the packed form, one stage deeper: header of chunk q + 2, planes of chunk
+        // q + 1 (<= 12 dwords per lane, usually 6-9) and the arithmetic of chunk q are in flight together
+        // No branch depends on whether the wave still has a chunk: past its last one it re-reads the cloud's
+        // last chunk with every lane masked (at most two wasted iterations per wave), so the compiler sees
+        // straight-line code and waits for the planes exactly once, where they are decoded.  (With a test of
+        // `have` around the loads it waited right behind the first plane load of every chunk.)
+        uint32_t d[12];
+        uint4 h0, h1;
+        uint32_t hc = 0, bx = 0, by = 0, bz = 0, i = 0;
+        bool hvalid = false, live = false;
+        auto fetch_hdr = [&](uint32_t q) {
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(q < R ? chunk_of(q) : nchunks));
+            hvalid = c < nchunks;
+            hc = hvalid ? c : nchunks - 1u;
+            h0 = pk_hdr[2 * (size_t)hc];
+            h1 = pk_hdr[2 * (size_t)hc + 1];
+        };
+        auto fetch_planes = [&]() {  // of the chunk whose header has arrived
+            i = hc * 64u + (uint32_t)lane;
+            live = hvalid && i < n4;
+            i = i < n4 ? i : n4 - 1u;  // (masked lanes: any valid address for the colour load)
+            bx = h0.x, by = h0.y, bz = h0.z;
+            load_planes(pk_planes, h0, h1, lane, d);
+        };
+        fetch_hdr(0);
+        fetch_planes();
+        fetch_hdr(1);
+        for (uint32_t q = 0; q < R; ++q) {
+            Rows r;
+            const bool live_c = live;
+            const uint32_t i_c = i;
+            const float4 X = unpack_axis(d, bx), Y = unpack_axis(d + 4, by), Z = unpack_axis(d + 8, bz);
+            project_rows(X, Y, Z, r);
+            fetch_planes();
+            fetch_hdr(q + 2);
+            do_quad(i_c, live_c, r);
+        }
+    } else if (!CULL) {
         // Software pipeline: the coordinates of the wave's NEXT quad are requested as soon as the current
         // ones have gone through the matrix rows, i.e. before the long part of an in-frustum quad (claims,
         // colour load, stores).  A wave waiting for its claims then still has three kilobyte-loads in
@@ -943,7 +1024,7 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
         for (uint32_t q = 0; q < R; ++q) {
             Rows r;
             const bool have_c = have, live_c = live;
-            const uint32_t i_c = i;
+            const uint32_t i_c = i < n4 ? i : n4 - 1u;  // (masked lanes past the end: any valid address for the colour load)
             if (have_c) project_rows(X, Y, Z, r);
             fetch(q + 1);
             if (have_c) do_quad(i_c, live_c, r);
@@ -994,7 +1075,16 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
                 const uint32_t i = chunk_of(g0 + (uint32_t)l) * 64u + (uint32_t)lane;
                 const bool live = i < n4;  // (lanes past the end of the cloud re-read its last quad, masked)
                 const uint32_t ic = live ? i : n4 - 1u;
-                const float4 X = ld_stream(x4 + ic), Y = ld_stream(y4 + ic), Z = ld_stream(z4 + ic);
+                float4 X, Y, Z;
+                if (PACKED) {
+                    const uint32_t cc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(i >> 6));
+                    const uint4 h0 = pk_hdr[2 * (size_t)cc], h1 = pk_hdr[2 * (size_t)cc + 1];
+                    uint32_t d[12];
+                    load_planes(pk_planes, h0, h1, lane, d);
+                    X = unpack_axis(d, h0.x), Y = unpack_axis(d + 4, h0.y), Z = unpack_axis(d + 8, h0.z);
+                } else {
+                    X = ld_stream(x4 + ic), Y = ld_stream(y4 + ic), Z = ld_stream(z4 + ic);
+                }
                 Rows r;
                 project_rows(X, Y, Z, r);
                 do_quad(ic, live, r);
@@ -1554,18 +1644,24 @@ void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int
     }
     // (hipExtLaunchKernelGGL with null events is a plain launch; with events the dispatch packet itself carries
     // the start / stop time stamps: no extra packets around the kernel, unlike hipEventRecord pairs)
-    const dim3 grid(point_grid(n4, c.grid)), block(kBlock);
-    const float4 *x = (const float4 *)c.x, *y = (const float4 *)c.y, *z = (const float4 *)c.z;
+    const bool packed = c.pk.hdr != nullptr;
+    // (a packed chunk is ~1.5 KB in flight per wave instead of 3 KB: a fifth workgroup per CU pays, 161 -> 155 us;
+    // the kernel's 89 registers admit five waves per SIMD)
+    const dim3 grid(point_grid(n4, packed && c.grid == kDefaultPointGrid ? kDefaultPointGrid * 5 / 4 : c.grid)), block(kBlock);
+    const float4 *x = packed ? (const float4 *)c.pk.hdr : (const float4 *)c.x;
+    const float4 *y = packed ? (const float4 *)c.pk.planes : (const float4 *)c.y, *z = (const float4 *)c.z;
     const uint4 *col = (const uint4 *)c.rgba;
-    if (bounds)
-        hipExtLaunchKernelGGL((k_project_bin<true, true>), grid, block, 0, s, ev_start, ev_stop, 0, x, y, z, col, (uint32_t)n4, P,
-                              W, H, S, bounds, clear_split, (uint32_t)phases, xp);
-    else if (c.incoherent)
-        hipExtLaunchKernelGGL((k_project_bin<false, false>), grid, block, 0, s, ev_start, ev_stop, 0, x, y, z, col, (uint32_t)n4,
-                              P, W, H, S, bounds, clear_split, (uint32_t)phases, xp);
-    else
-        hipExtLaunchKernelGGL((k_project_bin<false, true>), grid, block, 0, s, ev_start, ev_stop, 0, x, y, z, col, (uint32_t)n4,
-                              P, W, H, S, bounds, clear_split, (uint32_t)phases, xp);
+#define RTR_T1(CULL, GROUPS, PACKED)                                                                                          \
+    hipExtLaunchKernelGGL((k_project_bin<CULL, GROUPS, PACKED>), grid, block, 0, s, ev_start, ev_stop, 0, x, y, z, col,        \
+                          (uint32_t)n4, P, W, H, S, bounds, clear_split, (uint32_t)phases, xp)
+    if (bounds) {
+        if (packed) RTR_T1(true, true, true); else RTR_T1(true, true, false);
+    } else if (c.incoherent) {
+        if (packed) RTR_T1(false, false, true); else RTR_T1(false, false, false);
+    } else {
+        if (packed) RTR_T1(false, true, true); else RTR_T1(false, true, false);
+    }
+#undef RTR_T1
 }
 
 // bounding box of every 256-point chunk (the unit one wave of T1 handles per iteration):
@@ -1612,6 +1708,135 @@ void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds) {
                        (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, bounds);
 }
 
+
+// PackedXyz: measure (one wave per chunk: unsigned min / max of the bit patterns -> base and width per axis)
+__device__ __forceinline__ void chunk_bits(const uint4 *__restrict__ x4, const uint4 *__restrict__ y4,
+                                           const uint4 *__restrict__ z4, uint64_t n4, uint64_t c, int lane, uint32_t v[3][4]) {
+    uint64_t i = c * 64 + lane;
+    i = i < n4 ? i : n4 - 1;  // lanes past the end repeat the last quad (T1 masks them): they widen nothing
+    const uint4 q[3] = {x4[i], y4[i], z4[i]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        v[a][0] = q[a].x; v[a][1] = q[a].y; v[a][2] = q[a].z; v[a][3] = q[a].w;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_pack_measure(const uint4 *__restrict__ x4, const uint4 *__restrict__ y4,
+                                                         const uint4 *__restrict__ z4, uint64_t n4, uint4 *__restrict__ hdr,
+                                                         uint32_t *__restrict__ chunk_planes) {
+    const uint64_t nchunks = (n4 + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t c = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6; c < nchunks; c += ((uint64_t)gridDim.x * kBlock) >> 6) {
+        uint32_t v[3][4], lo[3], hi[3];
+        chunk_bits(x4, y4, z4, n4, c, lane, v);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = min(min(v[a][0], v[a][1]), min(v[a][2], v[a][3]));
+            hi[a] = max(max(v[a][0], v[a][1]), max(v[a][2], v[a][3]));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                lo[a] = min(lo[a], (uint32_t)__shfl_xor((int)lo[a], off, 64));
+                hi[a] = max(hi[a], (uint32_t)__shfl_xor((int)hi[a], off, 64));
+            }
+        }
+        if (lane == 0) {
+            uint32_t w[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const uint32_t r = hi[a] - lo[a];
+                w[a] = r == 0u ? 0u : (r < 0x100u ? 1u : (r < 0x10000u ? 2u : (r < 0x1000000u ? 3u : 4u)));
+            }
+            hdr[2 * c] = make_uint4(lo[0], lo[1], lo[2], w[0] | (w[1] << 3) | (w[2] << 6));
+            chunk_planes[c] = w[0] + w[1] + w[2];
+        }
+    }
+}
+// exclusive scan of the chunks' plane counts -> hdr[2 c + 1]; one workgroup (a one-off at upload: ~1 ms per 1e8 points)
+__global__ __launch_bounds__(512) void k_pack_scan(const uint32_t *__restrict__ chunk_planes, uint64_t nchunks,
+                                                   uint4 *__restrict__ hdr, uint64_t *__restrict__ total_planes) {
+    __shared__ uint32_t s_w[8];
+    uint64_t carry = 0;
+    for (uint64_t c0 = 0; c0 < nchunks; c0 += 512) {
+        const uint64_t c = c0 + threadIdx.x;
+        const uint32_t v = c < nchunks ? chunk_planes[c] : 0u;
+        uint32_t tot = 0;
+        const uint32_t incl = block_scan(v, s_w, tot);
+        if (c < nchunks) {
+            const uint64_t off = carry + (incl - v);
+            hdr[2 * c + 1] = make_uint4((uint32_t)off, (uint32_t)(off >> 32), 0u, 0u);
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *total_planes = carry;
+}
+__global__ __launch_bounds__(kBlock) void k_pack_write(const uint4 *__restrict__ x4, const uint4 *__restrict__ y4,
+                                                       const uint4 *__restrict__ z4, uint64_t n4, const uint4 *__restrict__ hdr,
+                                                       uint32_t *__restrict__ planes) {
+    const uint64_t nchunks = (n4 + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t c = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6; c < nchunks; c += ((uint64_t)gridDim.x * kBlock) >> 6) {
+        uint32_t v[3][4];
+        chunk_bits(x4, y4, z4, n4, c, lane, v);
+        const uint4 h0 = hdr[2 * c], h1 = hdr[2 * c + 1];
+        const uint32_t base[3] = {h0.x, h0.y, h0.z};
+        uint32_t *p = planes + (((((uint64_t)h1.y) << 32) | (uint64_t)h1.x) << 6) + lane;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const uint32_t w = (h0.w >> (3 * a)) & 7u;
+            const uint32_t e[4] = {v[a][0] - base[a], v[a][1] - base[a], v[a][2] - base[a], v[a][3] - base[a]};
+            uint32_t d[4];
+            transpose_bytes(e, d);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (w > (uint32_t)j) p[64 * j] = d[j];
+            p += 64u * w;
+        }
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_pack_verify(const uint4 *__restrict__ x4, const uint4 *__restrict__ y4,
+                                                        const uint4 *__restrict__ z4, uint64_t n4, const uint4 *__restrict__ hdr,
+                                                        const uint32_t *__restrict__ planes, unsigned long long *mismatches) {
+    const uint64_t nchunks = (n4 + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    unsigned long long bad = 0;
+    for (uint64_t c = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6; c < nchunks; c += ((uint64_t)gridDim.x * kBlock) >> 6) {
+        uint32_t v[3][4], d[12];
+        chunk_bits(x4, y4, z4, n4, c, lane, v);
+        const uint4 h0 = hdr[2 * c], h1 = hdr[2 * c + 1];
+        load_planes(planes, h0, h1, lane, d);
+        const float4 X = unpack_axis(d, h0.x), Y = unpack_axis(d + 4, h0.y), Z = unpack_axis(d + 8, h0.z);
+        const uint32_t got[3][4] = {{__float_as_uint(X.x), __float_as_uint(X.y), __float_as_uint(X.z), __float_as_uint(X.w)},
+                                    {__float_as_uint(Y.x), __float_as_uint(Y.y), __float_as_uint(Y.z), __float_as_uint(Y.w)},
+                                    {__float_as_uint(Z.x), __float_as_uint(Z.y), __float_as_uint(Z.z), __float_as_uint(Z.w)}};
+        if (c * 64 + lane < n4)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad += (got[0][k] != v[0][k] || got[1][k] != v[1][k] || got[2][k] != v[2][k]) ? 1ull : 0ull;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+static unsigned pack_grid(uint64_t n4) {
+    const uint64_t blocks = ((n4 + 63) / 64 + 3) / 4;
+    return (unsigned)(blocks < 8192 ? (blocks ? blocks : 1) : 8192);
+}
+void pack_measure(hipStream_t s, const Cloud &c, uint4 *hdr, uint32_t *chunk_planes, uint64_t *total_planes) {
+    const uint64_t n4 = (c.n + 3) / 4;
+    if (n4 == 0) return;
+    hipLaunchKernelGGL(k_pack_measure, dim3(pack_grid(n4)), dim3(kBlock), 0, s, (const uint4 *)c.x, (const uint4 *)c.y,
+                       (const uint4 *)c.z, n4, hdr, chunk_planes);
+    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(512), 0, s, chunk_planes, (n4 + 63) / 64, hdr, total_planes);
+}
+void pack_write(hipStream_t s, const Cloud &c, const uint4 *hdr, uint32_t *planes) {
+    const uint64_t n4 = (c.n + 3) / 4;
+    if (n4 == 0) return;
+    hipLaunchKernelGGL(k_pack_write, dim3(pack_grid(n4)), dim3(kBlock), 0, s, (const uint4 *)c.x, (const uint4 *)c.y,
+                       (const uint4 *)c.z, n4, hdr, planes);
+}
+void pack_verify(hipStream_t s, const Cloud &c, const uint4 *hdr, const uint32_t *planes, uint64_t *mismatches) {
+    const uint64_t n4 = (c.n + 3) / 4;
+    if (n4 == 0) return;
+    hipLaunchKernelGGL(k_pack_verify, dim3(pack_grid(n4)), dim3(kBlock), 0, s, (const uint4 *)c.x, (const uint4 *)c.y,
+                       (const uint4 *)c.z, n4, hdr, planes, (unsigned long long *)mismatches);
+}
 
 void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, float window, uint32_t *depth,
                  uint32_t *acc, uint8_t *img, int write_acc, const TilePyr *pyr, const Sliced *depth_slices) {

@@ -35,16 +35,21 @@ def _check_frame(pkg, orc, projector, xyzw, rgba, P, W, H, filtered=True):
     return ref
 
 
-@pytest.fixture(params=[1, 2, 0], ids=["tile", "tile-split", "two-pass"])
+@pytest.fixture(params=[1, 2, 3, 0], ids=["tile", "tile-split", "tile-packed", "two-pass"])
 def mode(request, projector):
     """tile-split: the binned form with the split threshold lowered to 64 entries, so that every
-    non-trivial tile of an ordinary test frame takes the several-workgroups-per-tile path."""
+    non-trivial tile of an ordinary test frame takes the several-workgroups-per-tile path.
+    tile-packed: option pack = 2, i.e. the point kernel reads the packed coordinates whatever the
+    cloud (the default only packs clouds that shrink by 1/8), and every upload is decoded and
+    compared with the SoA arrays on the device."""
     projector.set_option("mode", 1 if request.param else 0)
     if request.param == 2:
         projector.set_option("split_threshold", 64)
         projector.set_option("split_slice", 48)
+    projector.set_option("pack", 2 if request.param == 3 else 1)
     projector.set_option("keep_accum", 1)
     yield request.param
+    projector.set_option("pack", 1)
     projector.set_option("mode", 1)
     projector.set_option("split_threshold", 32768)
     projector.set_option("split_slice", 16384)
@@ -355,6 +360,58 @@ def test_adversarial_floats(pkg, orc, projector, mode):
         _check_frame(pkg, orc, projector, xyzw, rgba, orc.compose_projection(K, np.eye(4)), W, H)
     finally:
         projector.set_option("cull", 0)
+
+
+def test_pack_option(pkg, orc):
+    """Option "pack": the default packs a spatially ordered cloud (6-9 B/pt) and leaves a hash-ordered
+    one alone; 0 never packs, 2 always does (and verifies the decode on the device); switching it
+    re-packs the resident cloud at once.  Frames and rtr_download_points never change."""
+    n, W, H = 300_000, 640, 480
+    p = pkg.Projector(0)
+    try:
+        p.set_resolution(W, H)
+        p.set_option("auto_reorder", 0)
+        for scene, expect in (("room_shell", 1), ("uniform_box", 0)):
+            xyzw, rgba = orc.generate(scene, 21, 0, n, n)
+            P = pkg.orbit_projection(40, W, H)
+            ref = orc.project(xyzw, rgba, P, W, H)
+            for pack in (1, 0, 2, 1):
+                p.set_option("pack", pack)
+                if pack == 1:
+                    p.upload_points(xyzw, rgba)       # (0 and 2 re-pack the resident cloud)
+                want = {0: 0, 1: expect, 2: 1}[pack]
+                assert p.get_option("packed") == want, (scene, pack)
+                mb = p.get_option("packed_millibytes_per_point")
+                assert (mb < 10500) if (want and pack == 1) else (mb <= 12200), (scene, pack, mb)
+                assert (mb == 12000) == (want == 0)
+                img, depth = p.project(P)
+                assert np.array_equal(depth.view(np.uint32), ref["depth_bits"]), (scene, pack)
+                assert np.array_equal(img, ref["img"]), (scene, pack)
+                back, cols = p.download_points()
+                assert np.array_equal(back.view(np.uint32), xyzw.view(np.uint32)) and np.array_equal(cols, rgba)
+        # every width class in one cloud: constant axes, 1-, 2-, 3-byte ranges, sign changes, NaN / inf / -0
+        rng = np.random.default_rng(8)
+        m = 256 * 40 + 77
+        xyz = np.empty((m, 3), np.float32)
+        base = np.float32(2.0).view(np.uint32)
+        for c in range(0, m, 256):
+            k = min(256, m - c)
+            for a in range(3):
+                span = [1, 200, 60000, 1 << 23, 1 << 31][(c // 256 + a) % 5]
+                xyz[c:c + k, a] = (base + rng.integers(0, span, size=k, dtype=np.uint64).astype(np.uint32)).view(np.float32)
+        xyz[5, 0], xyz[6, 1], xyz[7, 2], xyz[300, 0] = np.nan, np.inf, -0.0, -1.5
+        xyzw, rgba = cloud(xyz, rng.integers(0, 256, size=(m, 3), dtype=np.uint8))
+        p.set_option("pack", 2)
+        p.upload_points(xyzw, rgba)
+        assert p.get_option("packed") == 1
+        K = np.array([[100.0, 0, 320], [0, 100.0, 240], [0, 0, 1]])
+        P = orc.compose_projection(K, np.eye(4))
+        ref = orc.project(xyzw, rgba, P, W, H)
+        img, depth = p.project(P)
+        assert np.array_equal(depth.view(np.uint32), ref["depth_bits"]) and np.array_equal(img, ref["img"])
+        assert (ref["depth_bits"] != orc.EMPTY_DEPTH).sum() > 100
+    finally:
+        p.close()
 
 
 def test_auto_reorder_option(pkg, orc):
