@@ -722,7 +722,7 @@ static int pack_cloud(rtr_ctx *c) {
     if (hipStreamSynchronize(c->stream) != hipSuccess) return give_up();
     const uint64_t bytes = host[0] * 256 + nchunks * 32;
     if (c->opt_pack == 1 && bytes * 8 > n4 * 48 * 7) return give_up();  // saves less than 1/8 of the 12 B/pt stream
-    // (one spare plane: the point kernel reads a chunk's first plane even when the chunk has none)
+    // (one spare plane: the last lane's 16-byte load runs up to 12 bytes past the chunk's last value)
     if (hipMalloc((void **)&planes, (host[0] + 1) * 256) != hipSuccess) return give_up();
     if (hipMemsetAsync(planes + host[0] * 64, 0, 256, c->stream) != hipSuccess) return give_up();
     rtr::pack_write(c->stream, cl, hdr, planes);

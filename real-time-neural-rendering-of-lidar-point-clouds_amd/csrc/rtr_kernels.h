@@ -15,14 +15,15 @@ struct Proj {
 
 // Lossless resident form of the coordinates for the tile-binned point kernel (option "pack").  A chunk =
 // 256 consecutive points = what one wave handles per iteration (lane l: points 4 l .. 4 l + 3).  Per
-// chunk and axis the fp32 BIT PATTERNS are stored as base + delta, base = the chunk's smallest pattern
-// (unsigned), delta in w = 0..4 bytes (0: the axis is constant in the chunk; 4: anything -- NaNs, mixed
-// signs).  Byte j of the four deltas of a lane forms one dword of "plane" j, and a plane is the 64
-// dwords of the wave (256 contiguous bytes): a chunk is wx + wy + wz planes, x planes first.
+// chunk and axis the fp32 BIT PATTERNS are stored as base | low bytes: base = the leading bits all 256
+// patterns share (low 8 w bits clear), w = 0..4 the number of bytes below that common prefix (0: the axis
+// is constant in the chunk; 4: nothing is shared -- NaNs, mixed signs).  An axis block is the 256 values'
+// low w bytes back to back (lane l's four values at byte 4 w l): 256 w bytes, read with ONE unaligned
+// 16-byte load per lane; a chunk is its x, y, z blocks = wx + wy + wz "planes" of 256 bytes.
 // hdr[2 c] = {base x, base y, base z, wx | wy << 3 | wz << 6}, hdr[2 c + 1] = {first plane (lo, hi), 0, 0}.
-// The plane buffer ends with one spare plane (a chunk's first plane is readable even if it has none).
+// The plane buffer ends with one spare plane (the last lane's 16-byte load runs past its values).
 // Spatially ordered clouds need 2-3 bytes per coordinate (neighbours share sign, exponent and leading
-// mantissa bits): 6-9 B/pt instead of 12, decoded with 12 byte-permutes and 4 adds per axis.
+// mantissa bits): 6-9 B/pt instead of 12, decoded with one byte-permute per value.
 struct PackedXyz {
     const uint4 *hdr;        // null: not packed
     const uint32_t *planes;

@@ -506,7 +506,8 @@ __device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split) 
     uint4 *const records = reinterpret_cast<uint4 *>(ts_items(S));
     RTR_STAMP(S, 1);
     const StoreConsts sc = *ts_consts(S);
-    uint32_t *const depth = sc.depth, *const acc = sc.acc, *const occ = sc.occ;
+    typedef uint32_t __attribute__((address_space(1))) *gu32_t;  // (pointers out of memory: global, not flat)
+    const gu32_t depth = (gu32_t)sc.depth, acc = (gu32_t)sc.acc, occ = (gu32_t)sc.occ;
     const uint32_t heavy = sc.heavy;
 #ifdef RTR_EXPERIMENT
     if (threadIdx.x == 0 && heavy != 7u) ts_dbg(S)[5] = wall_clock64();  // consts have arrived
@@ -657,7 +658,7 @@ __device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split) 
                 if (x < W && y < H) {
                     const size_t gp = (size_t)y * W + x;
                     depth[gp] = RTR_EMPTY;
-                    reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(0u, 0u, 0u, 0u);
+                    acc[4 * gp] = 0u, acc[4 * gp + 1] = 0u, acc[4 * gp + 2] = 0u, acc[4 * gp + 3] = 0u;
                 }
             }
         };
@@ -700,41 +701,59 @@ __device__ void next_frame_order(const TileStore &S) {
 }
 
 // PackedXyz helpers ---------------------------------------------------------------
-// 4 x 4 byte transpose: out[j] = (byte j of in[0], byte j of in[1], byte j of in[2], byte j of in[3]).
-// Deltas of a lane's four points <-> its dwords in planes 0..3; its own inverse.  v_perm_b32(S0, S1, sel):
-// selector 0-3 picks a byte of S1 (the second argument), 4-7 a byte of S0.
-__device__ __forceinline__ void transpose_bytes(const uint32_t in[4], uint32_t out[4]) {
-    const uint32_t t0 = __builtin_amdgcn_perm(in[1], in[0], 0x05010400u), t1 = __builtin_amdgcn_perm(in[1], in[0], 0x07030602u);
-    const uint32_t t2 = __builtin_amdgcn_perm(in[3], in[2], 0x05010400u), t3 = __builtin_amdgcn_perm(in[3], in[2], 0x07030602u);
-    out[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
-    out[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
-    out[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
-    out[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+// One UNALIGNED 16-byte load per axis and lane, whatever the width: lane l's four w-byte values start at
+// byte 4 w l of the axis block, so the load covers them (and up to 12 bytes of its neighbour's -- the buffer
+// ends with spare bytes).  A fixed number of loads per chunk, no branch around any of them.
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+struct AxisRaw { uint32_t d[4]; };
+__device__ __forceinline__ AxisRaw ld_axis(const uint8_t *block, uint32_t w, int lane) {
+    const u32x4_a4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4 *>(block + 4u * w * (uint32_t)lane));
+    return AxisRaw{{v.x, v.y, v.z, v.w}};
 }
-__device__ __forceinline__ uint32_t ld_stream_u32(const uint32_t *p) { return __builtin_nontemporal_load(p); }
-// the (up to) twelve plane dwords of lane `lane` of the chunk with header words h0, h1; the branches are
-// wave-uniform.  (Always issuing twelve loads -- absent planes re-reading a line the wave fetches anyway, or a
-// shared block of zeros -- would let the compiler count the loads and keep two chunks in flight, but the extra
-// load instructions cost more than that gains: 208 and 309 us against 161.)
-__device__ __forceinline__ void load_planes(const uint32_t *__restrict__ planes, const uint4 &h0, const uint4 &h1, int lane,
-                                            uint32_t d[12]) {
-    const uint32_t *p = planes + (((((uint64_t)h1.y) << 32) | (uint64_t)h1.x) << 6) + lane;
+// v_perm_b32(S0, S1, sel): selector byte 0-3 picks a byte of S1 (the second argument), 4-7 a byte of S0.
+// base has its low 8 w bits clear; value k = base | bytes [k w, k w + w) of the lane's 16 bytes: one permute
+// per value (two for the 3-byte values that straddle a dword).  w is wave-uniform.
+__device__ __forceinline__ float4 unpack_axis(const AxisRaw &r, uint32_t w, uint32_t base) {
+    uint32_t x[4];
+    if (w == 0u) {
+        x[0] = x[1] = x[2] = x[3] = base;
+    } else if (w == 3u) {
+        x[0] = __builtin_amdgcn_perm(base, r.d[0], 0x07020100u);
+        x[1] = __builtin_amdgcn_perm(base, __builtin_amdgcn_alignbit(r.d[1], r.d[0], 24), 0x07020100u);
+        x[2] = __builtin_amdgcn_perm(base, __builtin_amdgcn_alignbit(r.d[2], r.d[1], 16), 0x07020100u);
+        x[3] = __builtin_amdgcn_perm(base, r.d[2], 0x07030201u);
+    } else if (w == 2u) {
+        x[0] = __builtin_amdgcn_perm(base, r.d[0], 0x07060100u);
+        x[1] = __builtin_amdgcn_perm(base, r.d[0], 0x07060302u);
+        x[2] = __builtin_amdgcn_perm(base, r.d[1], 0x07060100u);
+        x[3] = __builtin_amdgcn_perm(base, r.d[1], 0x07060302u);
+    } else if (w == 1u) {
+        x[0] = __builtin_amdgcn_perm(base, r.d[0], 0x07060500u);
+        x[1] = __builtin_amdgcn_perm(base, r.d[0], 0x07060501u);
+        x[2] = __builtin_amdgcn_perm(base, r.d[0], 0x07060502u);
+        x[3] = __builtin_amdgcn_perm(base, r.d[0], 0x07060503u);
+    } else {
+        x[0] = r.d[0], x[1] = r.d[1], x[2] = r.d[2], x[3] = r.d[3];
+    }
+    return make_float4(__uint_as_float(x[0]), __uint_as_float(x[1]), __uint_as_float(x[2]), __uint_as_float(x[3]));
+}
+struct ChunkRaw { AxisRaw a[3]; };
+__device__ __forceinline__ ChunkRaw load_chunk(const uint32_t *__restrict__ planes, const uint4 &h0, const uint4 &h1, int lane) {
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(planes) + (((((uint64_t)h1.y) << 32) | (uint64_t)h1.x) << 8);
+    ChunkRaw c;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const uint32_t w = (h0.w >> (3 * a)) & 7u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            d[4 * a + j] = 0u;
-            if (w > (uint32_t)j) d[4 * a + j] = ld_stream_u32(p + 64 * j);
-        }
-        p += 64u * w;
+        c.a[a] = ld_axis(p, w, lane);
+        p += 256u * w;
     }
+    return c;
 }
-__device__ __forceinline__ float4 unpack_axis(const uint32_t planes[4], uint32_t base) {  // absent planes are 0
-    uint32_t e[4];
-    transpose_bytes(planes, e);
-    return make_float4(__uint_as_float(base + e[0]), __uint_as_float(base + e[1]), __uint_as_float(base + e[2]),
-                       __uint_as_float(base + e[3]));
+__device__ __forceinline__ void unpack_chunk(const ChunkRaw &c, uint32_t widths, uint32_t bx, uint32_t by, uint32_t bz, float4 &X,
+                                             float4 &Y, float4 &Z) {
+    X = unpack_axis(c.a[0], widths & 7u, bx);
+    Y = unpack_axis(c.a[1], (widths >> 3) & 7u, by);
+    Z = unpack_axis(c.a[2], (widths >> 6) & 7u, bz);
 }
 
 // T1 ------------------------------------------------------------------------------
@@ -803,8 +822,8 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
     auto chunk_of = [&](uint32_t q) -> uint32_t {  // q-th chunk of this wave, q < R (>= nchunks: none)
         uint32_t r = q + phase;
         r = r >= R ? r - R : r;
-        const uint64_t c = (uint64_t)r * NW + wave;
-        return (q < R && c < nchunks) ? (uint32_t)c : nchunks;
+        const uint32_t c = r * NW + wave;  // (< nchunks + NW < 2^25: a context holds < 2^32 points)
+        return (q < R && c < nchunks) ? c : nchunks;
     };
     // one quad (four points per lane) of the wave; every exit is wave-uniform
     // the three matrix rows for the four points of a lane (render.cu:33-40); X, Y, Z are dead afterwards
@@ -820,16 +839,19 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
     };
     auto do_quad = [&](uint32_t i, bool live, const Rows &r) {
         const float *rx = r.rx, *ry = r.ry, *rz = r.rz;
-        bool front = false;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) front = front || (rz[k] > 0.0f);  // render.cu:63 (NaN fails)
-        front = front && live;
+        // (the kernel is bound by instruction issue once the coordinates are packed: one max3 + max + compare
+        // instead of four compares and their combination; fmaxf skips NaNs, and an all-NaN quad compares false)
+        const bool front = live && (fmaxf(fmaxf(rz[0], rz[1]), fmaxf(rz[2], rz[3])) > 0.0f);  // render.cu:63
         if (__ballot(front) == 0ull) return;
         bool maybe[4], any = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float z = rz[k], lo = f_mul(-0.75f, z);
-            const bool out = (z > 1e-30f) && ((rx[k] < lo) || (rx[k] > f_mul(hiW, z)) || (ry[k] < lo) || (ry[k] > f_mul(hiH, z)));
+            // branch-free: the four margins as fused multiply-adds (one rounding each, < 1e-3 z against margins of
+            // 0.25 z: still conservative), their minimum, one compare.  A NaN margin is skipped by fminf: the
+            // point then stays a candidate and the exact arithmetic below decides.
+            const float z = rz[k];
+            const float m = fminf(fminf(fmaf(hiW, z, -rx[k]), fmaf(hiH, z, -ry[k])), fminf(fmaf(0.75f, z, rx[k]), fmaf(0.75f, z, ry[k])));
+            const bool out = (z > 1e-30f) && (m < 0.0f);
             maybe[k] = live && (z > 0.0f) && !out;
             any = any || maybe[k];
         }
@@ -956,7 +978,10 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
             for (int k = 0; k < 4; ++k)
                 if (in[k]) {
                     uint64_t *slot = v[k] < kS0 ? S.ext0 + ((size_t)st[k] << kS0Shift) + v[k] : extent_slot(S, st[k], v[k], own[k]);
-                    if (slot) *slot = make_entry(__float_as_uint(rz[k]), pix[k], cs[k]);
+                    // (a pointer that comes out of memory is "flat" to the compiler; say that it is global memory: with
+                    // a flat store possibly in flight every wait of the kernel becomes a full drain)
+                    typedef uint64_t __attribute__((address_space(1))) *gslot_t;
+                    if (slot) *(gslot_t)slot = make_entry(__float_as_uint(rz[k]), pix[k], cs[k]);
                 }
         }
     };
@@ -966,11 +991,10 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
         // q + 1 (<= 12 dwords per lane, usually 6-9) and the arithmetic of chunk q are in flight together
         // No branch depends on whether the wave still has a chunk: past its last one it re-reads the cloud's
         // last chunk with every lane masked (at most two wasted iterations per wave), so the compiler sees
-        // straight-line code and waits for the planes exactly once, where they are decoded.  (With a test of
-        // `have` around the loads it waited right behind the first plane load of every chunk.)
-        uint32_t d[12];
+        // straight-line code and waits for the chunk's three loads exactly once, where they are decoded.
+        ChunkRaw raw;
         uint4 h0, h1;
-        uint32_t hc = 0, bx = 0, by = 0, bz = 0, i = 0;
+        uint32_t hc = 0, bx = 0, by = 0, bz = 0, ww = 0, i = 0;
         bool hvalid = false, live = false;
         auto fetch_hdr = [&](uint32_t q) {
             const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(q < R ? chunk_of(q) : nchunks));
@@ -983,8 +1007,8 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
             i = hc * 64u + (uint32_t)lane;
             live = hvalid && i < n4;
             i = i < n4 ? i : n4 - 1u;  // (masked lanes: any valid address for the colour load)
-            bx = h0.x, by = h0.y, bz = h0.z;
-            load_planes(pk_planes, h0, h1, lane, d);
+            bx = h0.x, by = h0.y, bz = h0.z, ww = h0.w;
+            raw = load_chunk(pk_planes, h0, h1, lane);
         };
         fetch_hdr(0);
         fetch_planes();
@@ -993,7 +1017,8 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
             Rows r;
             const bool live_c = live;
             const uint32_t i_c = i;
-            const float4 X = unpack_axis(d, bx), Y = unpack_axis(d + 4, by), Z = unpack_axis(d + 8, bz);
+            float4 X, Y, Z;
+            unpack_chunk(raw, ww, bx, by, bz, X, Y, Z);
             project_rows(X, Y, Z, r);
             fetch_planes();
             fetch_hdr(q + 2);
@@ -1079,9 +1104,8 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
                 if (PACKED) {
                     const uint32_t cc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(i >> 6));
                     const uint4 h0 = pk_hdr[2 * (size_t)cc], h1 = pk_hdr[2 * (size_t)cc + 1];
-                    uint32_t d[12];
-                    load_planes(pk_planes, h0, h1, lane, d);
-                    X = unpack_axis(d, h0.x), Y = unpack_axis(d + 4, h0.y), Z = unpack_axis(d + 8, h0.z);
+                    const ChunkRaw raw = load_chunk(pk_planes, h0, h1, lane);
+                    unpack_chunk(raw, h0.w, h0.x, h0.y, h0.z, X, Y, Z);
                 } else {
                     X = ld_stream(x4 + ic), Y = ld_stream(y4 + ic), Z = ld_stream(z4 + ic);
                 }
@@ -1726,26 +1750,24 @@ __global__ __launch_bounds__(kBlock) void k_pack_measure(const uint4 *__restrict
     const uint64_t nchunks = (n4 + 63) / 64;
     const int lane = threadIdx.x & 63;
     for (uint64_t c = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6; c < nchunks; c += ((uint64_t)gridDim.x * kBlock) >> 6) {
-        uint32_t v[3][4], lo[3], hi[3];
+        uint32_t v[3][4], diff[3], first[3];
         chunk_bits(x4, y4, z4, n4, c, lane, v);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            lo[a] = min(min(v[a][0], v[a][1]), min(v[a][2], v[a][3]));
-            hi[a] = max(max(v[a][0], v[a][1]), max(v[a][2], v[a][3]));
+            first[a] = (uint32_t)__shfl((int)v[a][0], 0, 64);
+            diff[a] = (v[a][0] ^ first[a]) | (v[a][1] ^ first[a]) | (v[a][2] ^ first[a]) | (v[a][3] ^ first[a]);
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                lo[a] = min(lo[a], (uint32_t)__shfl_xor((int)lo[a], off, 64));
-                hi[a] = max(hi[a], (uint32_t)__shfl_xor((int)hi[a], off, 64));
-            }
+            for (int off = 32; off > 0; off >>= 1) diff[a] |= (uint32_t)__shfl_xor((int)diff[a], off, 64);
         }
         if (lane == 0) {
-            uint32_t w[3];
+            uint32_t w[3], base[3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const uint32_t r = hi[a] - lo[a];
+            for (int a = 0; a < 3; ++a) {  // bytes below the common prefix of the chunk's 256 bit patterns
+                const uint32_t r = diff[a];
                 w[a] = r == 0u ? 0u : (r < 0x100u ? 1u : (r < 0x10000u ? 2u : (r < 0x1000000u ? 3u : 4u)));
+                base[a] = w[a] == 4u ? 0u : (first[a] >> (8u * w[a])) << (8u * w[a]);
             }
-            hdr[2 * c] = make_uint4(lo[0], lo[1], lo[2], w[0] | (w[1] << 3) | (w[2] << 6));
+            hdr[2 * c] = make_uint4(base[0], base[1], base[2], w[0] | (w[1] << 3) | (w[2] << 6));
             chunk_planes[c] = w[0] + w[1] + w[2];
         }
     }
@@ -1777,17 +1799,18 @@ __global__ __launch_bounds__(kBlock) void k_pack_write(const uint4 *__restrict__
         uint32_t v[3][4];
         chunk_bits(x4, y4, z4, n4, c, lane, v);
         const uint4 h0 = hdr[2 * c], h1 = hdr[2 * c + 1];
-        const uint32_t base[3] = {h0.x, h0.y, h0.z};
-        uint32_t *p = planes + (((((uint64_t)h1.y) << 32) | (uint64_t)h1.x) << 6) + lane;
+        uint32_t *p = planes + (((((uint64_t)h1.y) << 32) | (uint64_t)h1.x) << 6);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const uint32_t w = (h0.w >> (3 * a)) & 7u;
-            const uint32_t e[4] = {v[a][0] - base[a], v[a][1] - base[a], v[a][2] - base[a], v[a][3] - base[a]};
-            uint32_t d[4];
-            transpose_bytes(e, d);
+            // the lane's four values, low w bytes each, back to back: w dwords at dword w * lane of the axis block
+            unsigned __int128 blob = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (w > (uint32_t)j) p[64 * j] = d[j];
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t e = w == 4u ? v[a][k] : (v[a][k] & ((1u << (8u * w)) - 1u));
+                blob |= (unsigned __int128)e << (8u * w * (uint32_t)k);
+            }
+            for (uint32_t j = 0; j < w; ++j) p[w * (uint32_t)lane + j] = (uint32_t)(blob >> (32u * j));
             p += 64u * w;
         }
     }
@@ -1799,11 +1822,12 @@ __global__ __launch_bounds__(kBlock) void k_pack_verify(const uint4 *__restrict_
     const int lane = threadIdx.x & 63;
     unsigned long long bad = 0;
     for (uint64_t c = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6; c < nchunks; c += ((uint64_t)gridDim.x * kBlock) >> 6) {
-        uint32_t v[3][4], d[12];
+        uint32_t v[3][4];
         chunk_bits(x4, y4, z4, n4, c, lane, v);
         const uint4 h0 = hdr[2 * c], h1 = hdr[2 * c + 1];
-        load_planes(planes, h0, h1, lane, d);
-        const float4 X = unpack_axis(d, h0.x), Y = unpack_axis(d + 4, h0.y), Z = unpack_axis(d + 8, h0.z);
+        const ChunkRaw raw = load_chunk(planes, h0, h1, lane);
+        float4 X, Y, Z;
+        unpack_chunk(raw, h0.w, h0.x, h0.y, h0.z, X, Y, Z);
         const uint32_t got[3][4] = {{__float_as_uint(X.x), __float_as_uint(X.y), __float_as_uint(X.z), __float_as_uint(X.w)},
                                     {__float_as_uint(Y.x), __float_as_uint(Y.y), __float_as_uint(Y.z), __float_as_uint(Y.w)},
                                     {__float_as_uint(Z.x), __float_as_uint(Z.y), __float_as_uint(Z.z), __float_as_uint(Z.w)}};
