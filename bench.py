@@ -117,11 +117,21 @@ def frame_bytes(n_local, W, H, with_filter):
     return required, two_pass
 
 
-def roofline_of(kern_ms, launches, n_local, traffic, every):
+def roofline_of(kern_ms, launches, n_local, traffic, every, stream_bpp=12.0):
+    """`achieved` is the contract's figure: ALGORITHMIC bytes (12 B/pt, SURVEY.md 8d: fp32 xyz) / launch time.
+    The resident cloud may be smaller than that (option "pack": lossless, 6-9 B/pt for ordered clouds), so the
+    bytes the kernel really streams and their share of the HBM peak are stated next to it -- `frac` can
+    exceed what HBM could deliver for 12 B/pt, `resident_stream_frac` cannot."""
     achieved = 12.0 * n_local / (kern_ms * 1e-3) / 1e9  # GB/s: 12 B/pt streamed by the dominant kernel
+    resident = stream_bpp * n_local
     return {"bound": "hbm", "kernel": "min_depth (k_project_bin: stream + append)", "achieved": achieved,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": 12.0 * n_local, "avg_launch_ms": kern_ms, "launches_timed": int(launches),
+            "resident_stream_bytes_per_point": stream_bpp, "resident_stream_bytes_per_launch": resident,
+            "resident_stream_frac": resident / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "bound_note": ("coordinates read from the lossless packed form: the kernel is no longer HBM-bound but "
+                           "bound by instruction issue (rocprofv3 PMC: VALUBusy + SALUBusy ~ 90 %, DESIGN.md)")
+                          if stream_bpp < 11.9 else "coordinates read as fp32 SoA (12 B/pt)",
             "how": "HIP events on the kernel's stream inside the timed region, " +
                    ("every frame" if every == 1 else "every 4th frame") +
                    "; in the tile-binned form the two events are the start / stop stamps of the kernel's own "
@@ -379,6 +389,7 @@ def main():
         return {k: (ms / max(n, 1)) for k, (ms, n) in timing_.items() if n}
 
     dt, timing, exchange_info = run_exchange_forms(S, renderers, args.steps, args.warmup)
+    stream_bpp = S.projs[0].get_option("packed_millibytes_per_point") / 1000.0  # 12.0 unless the cloud is packed
     n_local = S.hi - S.lo
 
     # Reported separately (never part of `value`), N = 1 only.
@@ -437,7 +448,8 @@ def main():
                              "order_ratio": U.projs[0].get_option("order_ratio_ppm") / 1e6,
                              "roofline": roofline_of(ku["min_depth"], tu["min_depth"][1], args.points,
                                                      measured_traffic("uniform_box" if policy == 0 else "uniform_box_sorted",
-                                                                      args.points, W, H, with_filter), every),
+                                                                      args.points, W, H, with_filter), every,
+                                                     U.projs[0].get_option("packed_millibytes_per_point") / 1000.0),
                              "frame_required_bytes_frac": req / (dtu / m) / 1e9 / HBM_PEAK_GBS}
                 if t_up is not None:
                     ubox[key]["generate_plus_sort_s"] = t_up
@@ -492,11 +504,14 @@ def main():
                                                     depth_k))) if multi else
                        ("single GPU" + (", %d frames in flight" % depth_k if depth_k > 1 else ""))},
             "roofline": roofline_of(kern[dom], timing[dom][1], n_local,
-                                    measured_traffic(args.scene, n_local, W, H, with_filter), every),
+                                    measured_traffic(args.scene, n_local, W, H, with_filter), every, stream_bpp),
             # the frame against the bytes THIS design has to move (cloud streamed once: 12 B/pt, 39 B/px of
             # clear / resolve work, ~50 B/px of prefilter) ...
             "frame_required_bytes": required,
             "frame_required_bytes_frac": required / step_s / 1e9 / HBM_PEAK_GBS,
+            # ... the same with the coordinate stream at its RESIDENT size (packed clouds: what HBM really delivers)
+            "frame_resident_bytes": required - (12.0 - stream_bpp) * n_local,
+            "frame_resident_bytes_frac": (required - (12.0 - stream_bpp) * n_local) / step_s / 1e9 / HBM_PEAK_GBS,
             # ... and against SURVEY.md 8d's figure for the reference's two-pass structure (24 B/pt + 39 B/px;
             # its acceptance line is >= 0.70).  Not a roofline fraction: a one-pass frame can exceed 1.
             "vs_two_pass_bytes": two_pass / step_s / 1e9 / HBM_PEAK_GBS,

@@ -751,9 +751,22 @@ __device__ __forceinline__ ChunkRaw load_chunk(const uint32_t *__restrict__ plan
 }
 __device__ __forceinline__ void unpack_chunk(const ChunkRaw &c, uint32_t widths, uint32_t bx, uint32_t by, uint32_t bz, float4 &X,
                                              float4 &Y, float4 &Z) {
-    X = unpack_axis(c.a[0], widths & 7u, bx);
-    Y = unpack_axis(c.a[1], (widths >> 3) & 7u, by);
-    Z = unpack_axis(c.a[2], (widths >> 6) & 7u, bz);
+    // the width combinations of ordered clouds first, each one compare away from straight-line code: the
+    // per-axis chains cost ~12 scalar instructions per axis, and the kernel is bound by instruction issue
+    constexpr uint32_t k333 = 3u | (3u << 3) | (3u << 6), k033 = (3u << 3) | (3u << 6), k303 = 3u | (3u << 6), k330 = 3u | (3u << 3);
+    if (widths == k333) {
+        X = unpack_axis(c.a[0], 3u, bx), Y = unpack_axis(c.a[1], 3u, by), Z = unpack_axis(c.a[2], 3u, bz);
+    } else if (widths == k033) {
+        X = unpack_axis(c.a[0], 0u, bx), Y = unpack_axis(c.a[1], 3u, by), Z = unpack_axis(c.a[2], 3u, bz);
+    } else if (widths == k303) {
+        X = unpack_axis(c.a[0], 3u, bx), Y = unpack_axis(c.a[1], 0u, by), Z = unpack_axis(c.a[2], 3u, bz);
+    } else if (widths == k330) {
+        X = unpack_axis(c.a[0], 3u, bx), Y = unpack_axis(c.a[1], 3u, by), Z = unpack_axis(c.a[2], 0u, bz);
+    } else {
+        X = unpack_axis(c.a[0], widths & 7u, bx);
+        Y = unpack_axis(c.a[1], (widths >> 3) & 7u, by);
+        Z = unpack_axis(c.a[2], (widths >> 6) & 7u, bz);
+    }
 }
 
 // T1 ------------------------------------------------------------------------------
