@@ -47,6 +47,20 @@ for k in sorted(set(fetch) | set(write)):
     summ[k] = {"FETCH_SIZE_KiB_per_dispatch": f_, "WRITE_SIZE_KiB_per_dispatch": w_,
                "hbm_bytes_per_dispatch": 1024.0 * (2.0 * f_ + w_)}
 json.dump(summ, open(os.path.join(d, "pmc_fetch_write_summary.json"), "w"), indent=1)
+# instruction-issue counters (whatever the pmc_i* passes collected), per kernel and dispatch
+issue = {}
+for sub in ("pmc_i1", "pmc_i2"):
+    for f in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if not k.startswith(("k_project_bin", "k_tile", "k_filter4")):
+                continue
+            a = issue.setdefault(k, {}).setdefault(r["Counter_Name"], [0.0, 0])
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+if issue:
+    json.dump({k: {c: v[0] / max(v[1], 1) for c, v in cs.items()} for k, cs in issue.items()},
+              open(os.path.join(d, "pmc_issue_summary.json"), "w"), indent=1)
 frame = [r for r in rows if r[0].startswith(("k_project_bin", "k_tile", "k_filter4"))]
 print("frame kernels:", [(r[0], round(r[2], 1)) for r in frame], "sum_us", round(sum(r[2] for r in frame), 1))
 print("frame traffic GB:", round(sum(v["hbm_bytes_per_dispatch"] for k, v in summ.items()
