@@ -72,7 +72,7 @@ struct rtr_ctx {
     int opt_heavy = 32768;           // tiles with more entries are split over several workgroups in T4 ...
     int opt_slice = 16384;           // ... into slices of at least this many entries
     int opt_p2p_timeout_ms = 2000;   // peer-to-peer flag barriers give up after this long (option "p2p_timeout_ms")
-    int opt_fill_shift = 2;          // stream counters 2^2 words = 16 B apart (see "fill_shift")
+    int opt_fill_shift = 4;          // stream counters 2^4 words = 64 B apart (see "fill_shift")
     int opt_xp = 0;                  // RTR_EXPERIMENT builds only (tools/kbench.py)
     int opt_phases = 1;         // T1: phase groups of the grid stride (option "phases", see k_project_bin)
     int opt_probe = 0;          // rtr_stream_probe variant (experiments)
