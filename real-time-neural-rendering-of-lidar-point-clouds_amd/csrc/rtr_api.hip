@@ -977,7 +977,7 @@ int rtr_min_depth_pass(rtr_ctx *c, const float P[16]) {
         if (int rc = bin_points(c, P, false, c->p2p.whole_frame)) return rc;
         Timed t(c, RTR_K_TILE);
         rtr::launch_tile(c->stream, 1, c->W, c->H, c->F().store, c->prm.depth_window, c->depth, c->acc, c->img,
-                         c->p2p.whole_frame ? 2 : 0, nullptr);
+                         c->p2p.whole_frame ? 6 : 0, nullptr);  // 2: only writer, 4: tiles without entries are not written
         mark_consumed(c);
     } else {
         Timed t(c, RTR_K_MIN_DEPTH);
@@ -1015,7 +1015,7 @@ int rtr_accumulate_pass(rtr_ctx *c, const float P[16]) {
         c->p2p.depth_sliced = false;
         Timed t(c, RTR_K_TILE);
         rtr::launch_tile(c->stream, 2, c->W, c->H, c->F().store, c->prm.depth_window, c->depth, c->acc, c->img,
-                         c->p2p.whole_frame ? 2 : 0, pyr.enable ? &pyr : nullptr, dsl.chunk ? &dsl : nullptr);
+                         c->p2p.whole_frame ? 6 : 0, pyr.enable ? &pyr : nullptr, dsl.chunk ? &dsl : nullptr);
         mark_consumed(c);
     } else {
         Timed t(c, RTR_K_ACCUMULATE);

@@ -166,6 +166,9 @@ int order_quality(hipStream_t s, const float *bounds, uint64_t n, float *ratio);
 // T4: per-tile LDS z-buffer over the tile store.  mode 0 = whole frame (min + accumulate + resolve
 // of every unsplit tile, min phase of split tiles), 3 = second phase of the split tiles of a whole
 // frame, 1 = min only, 2 = accumulate only.
+// write_acc: bit 0 (mode 0) also write the accumulators; bit 1 (modes 1, 2) this launch is the only writer of
+// the frame buffer: store instead of folding into what memory holds; bit 2 (modes 1, 2; sharded frames)
+// tiles without entries are not written at all (the peers only read tiles of the occupancy bitmap).
 // depth_slices (mode 2 only): read the global depth from the ranks' reduced slices and store it to `depth`
 void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, float window, uint32_t *depth,
                  uint32_t *acc, uint8_t *img, int write_acc, const TilePyr *pyr, const Sliced *depth_slices = nullptr);

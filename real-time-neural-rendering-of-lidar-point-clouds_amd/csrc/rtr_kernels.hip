@@ -1256,6 +1256,10 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
     // MODE 1 / 2, bit 1: this launch is the only writer of the frame buffer (no rtr_clear before it):
     // store the tile's depth / sums instead of folding them into what memory holds
     const bool overwrite = (write_acc & 2) != 0;
+    // bit 2 (sharded frames, rtr_p2p_render): the peers read this rank's depth / accumulators only under the
+    // tiles its occupancy bitmap lists (T1's epilogue: tiles with entries), so a tile WITHOUT local entries
+    // is not written at all -- with N ranks ~(N - 1) / N of the tiles of a rank's two tile passes
+    const bool sparse = (write_acc & 4) != 0;
     write_acc &= 1;
     const uint4 *const records = reinterpret_cast<const uint4 *>(ts_items(S));
     // Records [0, ntiles): one tile each, for workgroups 0 .. ntiles - 1; records [ntiles, ...): the slices of
@@ -1286,6 +1290,8 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
         if (item == kItemSkip) break;  // a split tile's own slot (workgroup-uniform)
         const uint32_t sub = (item >> 12) & 1023u, nsub = (item >> 22) + 1u;
         const bool split = nsub > 1u;
+        const bool no_local = (MODE == 1 || MODE == 2) && sparse && (rec0.y + rec0.z + rec0.w + rec1.x) == 0u;
+        if (MODE == 1 && no_local) break;  // (workgroup-uniform; an unsplit tile's workgroup has this one item)
         const int tile = (int)(item & 4095u);
         const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
         const int tx0 = tx << g.tw_shift, ty0 = ty * kTileH;
@@ -1388,8 +1394,8 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
         // own word (so the count field never reads low), and the count cannot wrap below 65536
         // entries.  If any pixel ends with count > 257 the whole item is redone with the wide layout.
         unsigned long long *s_acc64 = reinterpret_cast<unsigned long long *>(s_acc);
-        bool narrow = do_acc && (n_local <= 60000u);
-        if (do_acc)
+        bool narrow = do_acc && !no_local && (n_local <= 60000u);
+        if (do_acc && !no_local)
             for (int p = tid; p < (narrow ? 2 : 4) * tpix; p += T) s_acc[p] = 0;
         auto min_one = [&](unsigned long long r, uint32_t pb) {  // render.cu:81, behind an early-z read: an LDS read
             // costs a fraction of an LDS atomic, and only a few entries per pixel lower its minimum.  (Indexing
@@ -1625,7 +1631,7 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
                 }
             }
         };
-        if (!split || (MODE == 3 && finish)) write_out();
+        if ((!split || (MODE == 3 && finish)) && !no_local) write_out();
         RTR_TSTAMP(5);
         if ((MODE == 0 && !split) || (MODE == 3 && finish)) {
             // (the barrier the image rows need anyway also carries the verdict on the packed accumulators: an
@@ -1892,9 +1898,9 @@ void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, floa
         hipLaunchKernelGGL(k_tile<3>, dim3(kSplitGrid), block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 1,
                            pyr ? *pyr : none, nosl);
     else if (mode == 1)
-        hipLaunchKernelGGL(k_tile<1>, grid1, block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 2, none, nosl);
+        hipLaunchKernelGGL(k_tile<1>, grid1, block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 6, none, nosl);
     else  // mode 2 always writes the accumulators; bit 1 of write_acc = overwrite; pyr: also emit the pyramid
-        hipLaunchKernelGGL(k_tile<2>, grid, block, lds, s, S, g, W, H, window, depth, acc, img, 1 | (write_acc & 2),
+        hipLaunchKernelGGL(k_tile<2>, grid, block, lds, s, S, g, W, H, window, depth, acc, img, 1 | (write_acc & 6),
                            pyr ? *pyr : none, depth_slices ? *depth_slices : nosl);
 }
 
