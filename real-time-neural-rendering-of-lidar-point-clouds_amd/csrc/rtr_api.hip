@@ -1074,7 +1074,11 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
     int rc;
     if (use_tiles(c)) {  // one launch does clear + min + accumulate + resolve per tile
         DevGuard g(c->device);
-        if ((rc = bin_points(c, P, c->opt_overlap && c->front, true))) return rc;
+        // (T1 beside the previous frame's tail must not touch the frame buffers: the split tiles' pixels are then
+        // reset by a launch of their own on the tail's stream)
+        const bool overlapped = c->opt_overlap && c->front;
+        if ((rc = bin_points(c, P, overlapped, !overlapped))) return rc;
+        if (overlapped && c->opt_heavy > 0) rtr::launch_reset_split(c->stream, c->W, c->H, c->F().store, c->depth, c->acc);
         // with the default four levels the tile kernel also emits the prefilter's pyramid and
         // min / max partials (F1) while the finished depth tile is still in LDS
         rtr::TilePyr pyr{};

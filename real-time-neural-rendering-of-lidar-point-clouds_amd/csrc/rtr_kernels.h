@@ -170,6 +170,9 @@ int order_quality(hipStream_t s, const float *bounds, uint64_t n, float *ratio);
 // the frame buffer: store instead of folding into what memory holds; bit 2 (modes 1, 2; sharded frames)
 // tiles without entries are not written at all (the peers only read tiles of the occupancy bitmap).
 // depth_slices (mode 2 only): read the global depth from the ranks' reduced slices and store it to `depth`
+// resets depth / accumulators under the tiles T1's epilogue decided to split (what the epilogue itself does when
+// launch_project_bin's clear_split is set); for frames whose T1 overlapped the previous frame's tail
+void launch_reset_split(hipStream_t s, int W, int H, const TileStore &S, uint32_t *depth, uint32_t *acc);
 void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, float window, uint32_t *depth,
                  uint32_t *acc, uint8_t *img, int write_acc, const TilePyr *pyr, const Sliced *depth_slices = nullptr);
 void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *sink, int variant);

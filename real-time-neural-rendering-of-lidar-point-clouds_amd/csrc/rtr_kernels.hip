@@ -1144,6 +1144,29 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
     if (s_last && RTR_XP(32) && threadIdx.x == 0) *ts_ticket(S) = 0u;  // (only together with xp 8: nothing was claimed)
 }
 
+// Option "overlap": T1 runs beside the previous frame's tail, which still reads and writes the frame buffers,
+// so its epilogue must not reset the split tiles' pixels (clear_split = 0); this launch does it on the tail's
+// stream instead, right before the tile kernel (one workgroup per tile, only split tiles do anything).
+__global__ __launch_bounds__(kBlock) void k_reset_split(int W, int H, TileStore S, uint32_t *__restrict__ depth,
+                                                        uint32_t *__restrict__ acc) {
+    const TileGeom g = tile_geom(W, H);
+    const int tile = blockIdx.x;
+    if (ts_tile_cnt(S)[tile] <= ts_consts(S)->heavy) return;
+    const int tw = 1 << g.tw_shift, tpix = 32 << g.tw_shift;
+    const int tx0 = (tile % g.tiles_x) << g.tw_shift, ty0 = (tile / g.tiles_x) * kTileH;
+    for (int p = threadIdx.x; p < tpix; p += kBlock) {
+        const int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
+        if (x < W && y < H) {
+            const size_t gp = (size_t)y * W + x;
+            depth[gp] = RTR_EMPTY;
+            reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+}
+void launch_reset_split(hipStream_t s, int W, int H, const TileStore &S, uint32_t *depth, uint32_t *acc) {
+    hipLaunchKernelGGL(k_reset_split, dim3(tile_geom(W, H).ntiles), dim3(kBlock), 0, s, W, H, S, depth, acc);
+}
+
 // frames without points: the epilogue alone
 __global__ __launch_bounds__(kBlock) void k_bin_empty(int W, int H, TileStore S, int clear_split) {
     bin_epilogue(S, W, H, clear_split);

@@ -509,18 +509,21 @@ def test_ten_million_points_in_one_tile(pkg, orc, projector):
     assert int(ref["acc"][..., 3].sum()) > 0
 
 
-@pytest.mark.parametrize("tail_cus", [0, 8])
-def test_overlap_option_keeps_every_frame(pkg, orc, projector, tail_cus):
-    """Option "overlap": T1 of a whole-frame render runs on a second stream and fills the list /
-    bin set the tail of the previous frame is not reading (optionally with disjoint CU masks).
+@pytest.mark.parametrize("tail_cus,split", [(0, 32768), (8, 32768), (0, 64)])
+def test_overlap_option_keeps_every_frame(pkg, orc, projector, tail_cus, split):
+    """Option "overlap": T1 of a whole-frame render runs on a second stream and fills the tile
+    store the tail of the previous frame is not reading (optionally with disjoint CU masks).
     Frames queued back to back without synchronisation, mixed with phase calls and a new cloud,
-    stay bit-identical to the oracle."""
+    stay bit-identical to the oracle -- also when tiles are split (their pixels are then reset on
+    the tail's stream, not by T1 beside the previous frame's tail: found by tools/fuzz_parity.py)."""
     W, H = 640, 480
     xyzw, rgba = orc.generate("room_shell", 77, 0, 300_000, 300_000)
     poses = [pkg.orbit_projection(k, W, H) for k in range(12)]
     projector.upload_points(xyzw, rgba)
     projector.set_resolution(W, H)
     projector.set_option("tail_cus", tail_cus)
+    projector.set_option("split_threshold", split)
+    projector.set_option("split_slice", max(16, split // 2))
     try:
         projector.set_option("overlap", 1)
     except pkg.RtrError:
@@ -562,6 +565,8 @@ def test_overlap_option_keeps_every_frame(pkg, orc, projector, tail_cus):
     finally:
         projector.set_option("overlap", 0)
         projector.set_option("tail_cus", 0)
+        projector.set_option("split_threshold", 32768)
+        projector.set_option("split_slice", 16384)
 
 
 def test_compute_full_handoff(pkg, orc, monkeypatch, tmp_path):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: randomized parity sweep (resolutions, point counts, scenes, poses, modes, culling,
-reorder, filter, pyramid depth and filter parameters, option overlap) of the HIP path against the
-oracle.  Exit code 1 on the first mismatch."""
+reorder, packed coordinates, split thresholds, filter, pyramid depth and filter parameters, option
+overlap) of the HIP path against the oracle.  Exit code 1 on the first mismatch."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,8 +37,12 @@ for it in range(cases):
         P = pkg.compose_projection(K, E)
     else:
         P = pkg.orbit_projection(int(rng.integers(0, 1000)), W, H)
+    pack = int(rng.choice([0, 1, 2, 2]))            # 2: packed whatever the cloud, decode verified on the device
+    split = int(rng.choice([32768, 32768, 64, 1000]))
     p.set_option("mode", mode); p.set_option("cull", cull)
     p.set_option("overlap", overlap)
+    p.set_option("pack", pack)
+    p.set_option("split_threshold", split); p.set_option("split_slice", max(16, split // 2))
     p.set_params(depth_window=prm.depth_window, filter_strength=prm.filter_strength,
                  gradient_threshold=prm.gradient_threshold, levels=levels)
     p.upload_points(xyzw, rgba)
@@ -59,8 +63,20 @@ for it in range(cases):
               np.array_equal(p.download(L.BUF_MASK), rf["mask"]) and np.array_equal(p.download(L.BUF_MINMAX), rf["minmax"]))
     if not ok:
         print("MISMATCH", dict(it=it, W=W, H=H, n=n, scene=scene, mode=mode, cull=cull, reorder=reorder, filt=filt,
-                               levels=levels, overlap=overlap, window=prm.depth_window, strength=prm.filter_strength,
+                               levels=levels, overlap=overlap, pack=pack, split=split, window=prm.depth_window, strength=prm.filter_strength,
                                thr=prm.gradient_threshold))
+        if os.environ.get("FUZZ_DIAG"):  # which option makes the difference (same cloud, same pose)
+            for key, val in (("overlap", 0), ("pack", 0), ("split_threshold", 32768), ("cull", 0), ("mode", 0)):
+                p.set_option(key, val)
+                if key == "split_threshold":
+                    p.set_option("split_slice", 16384)
+                i3, d3 = p.project(P)
+                okp = np.array_equal(d3.view(np.uint32), ref["depth_bits"]) and np.array_equal(i3, ref["img"])
+                okf = None
+                if filt:
+                    i4, d4 = p.project(P, filtered=True)
+                    okf = np.array_equal(d4.view(np.uint32), rf["depth"].view(np.uint32)) and np.array_equal(i4, rf["img"])
+                print("  after", key, "=", val, ": plain frame", okp, "filtered", okf, p.frame_stats() if p.get_option("mode") else "", flush=True)
         sys.exit(1)
     if it % 25 == 0:
         print("case", it, "ok", round(time.time() - t0, 1), "s", flush=True)
