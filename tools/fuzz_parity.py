@@ -18,6 +18,9 @@ for it in range(cases):
     if levels == 5:
         W = max(32, W // 32 * 32)
     H = int(rng.integers(max(16, 1 << levels), 1300))
+    if os.environ.get("FUZZ_4K"):  # frames beyond 4096 tiles of 32x32: the 64-wide processing tiles (4 streams each)
+        W = int(rng.choice([3840, 4096, 4224, 5120]))
+        H = int(rng.integers(2100, 2900))
     prm = orc.default_params()
     prm.levels = levels
     if rng.random() < 0.3:
