@@ -1252,6 +1252,27 @@ __device__ __forceinline__ void tile_pyramid(const uint32_t *s_depth, uint32_t *
 }
 
 
+// The three truncating divisions of the resolve (render.cu:147-162) with ONE reciprocal: for count < 2^16 the
+// sums are < 2^24, exact as floats; sum * rcp(count) is within 1e-4 of the quotient (v_rcp_f32: 1 ulp), so its
+// floor is the exact quotient or one off, which the remainder settles.  The u32 division the compiler
+// expands costs ~20 vector instructions each, and the tile kernel is half VALU-bound.
+__device__ __forceinline__ uint8_t quot_u8(uint32_t a, uint32_t c, float rc) {
+    uint32_t q = (uint32_t)((float)a * rc);
+    const int32_t r = (int32_t)(a - q * c);
+    q = r < 0 ? q - 1u : ((uint32_t)r >= c ? q + 1u : q);
+    return (uint8_t)q;
+}
+__device__ __forceinline__ void resolve3(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t c, uint8_t &q0, uint8_t &q1, uint8_t &q2) {
+    if (c == 0u) {
+        q0 = q1 = q2 = 0;
+    } else if (c < 65536u) {
+        const float rc = __builtin_amdgcn_rcpf((float)c);
+        q0 = quot_u8(a0, c, rc), q1 = quot_u8(a1, c, rc), q2 = quot_u8(a2, c, rc);
+    } else {
+        q0 = (uint8_t)(a0 / c), q1 = (uint8_t)(a1 / c), q2 = (uint8_t)(a2 / c);
+    }
+}
+
 // T4: per-tile LDS z-buffer.  MODE 0 = whole frame (min + accumulate + resolve, writes
 // depth / image / optionally the accumulators; for a split tile only the min phase), MODE 3 = the
 // second phase of the split tiles of a whole frame; MODE 1 = min only (depth = min(depth,
@@ -1647,9 +1668,11 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
                         }
                     } else {
                         if (MODE == 0 && inb && write_acc) reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(a0, a1, a2, c);
-                        s_rgb[3 * p + 0] = c ? (uint8_t)(a0 / c) : 0;  // render.cu:147-162
-                        s_rgb[3 * p + 1] = c ? (uint8_t)(a1 / c) : 0;
-                        s_rgb[3 * p + 2] = c ? (uint8_t)(a2 / c) : 0;
+                        uint8_t q0, q1, q2;
+                        resolve3(a0, a1, a2, c, q0, q1, q2);  // render.cu:147-162
+                        s_rgb[3 * p + 0] = q0;
+                        s_rgb[3 * p + 1] = q1;
+                        s_rgb[3 * p + 2] = q2;
                     }
                 }
             }
