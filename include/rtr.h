@@ -107,7 +107,9 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *  "point_grid": workgroups of the grid-stride point kernels (default 1024 = 4 per CU; at the default the
  *          tile-binned point kernel takes 1280 when it reads packed coordinates).
  *  "phases": the point kernel's workgroups are cut into this many groups that start at different
- *          places of the cloud (default 1: measured best); "fill_shift": the per-tile stream counters
+ *          places of the cloud (default 0 = automatic: 1, which keeps one dense streaming front, unless the
+ *          previous frame had more than a quarter of the cloud inside the frustum, then 16 -- the claims of
+ *          a distant overview spread over more stream counters); "fill_shift": the per-tile stream counters
  *          lie 4 << value bytes apart (default 4 = 64 bytes; packed counters share memory channels and queue
  *          up: a distant overview with every point in a dozen tiles takes 3.0 ms in the point kernel at 2,
  *          1.5 ms at 4, for +1 % on an ordinary view).

@@ -74,7 +74,7 @@ struct rtr_ctx {
     int opt_p2p_timeout_ms = 2000;   // peer-to-peer flag barriers give up after this long (option "p2p_timeout_ms")
     int opt_fill_shift = 4;          // stream counters 2^4 words = 64 B apart (see "fill_shift")
     int opt_xp = 0;                  // RTR_EXPERIMENT builds only (tools/kbench.py)
-    int opt_phases = 1;         // T1: phase groups of the grid stride (option "phases", see k_project_bin)
+    int opt_phases = 0;         // T1: phase groups of the grid stride (option "phases", see k_project_bin); 0 = automatic
     int opt_probe = 0;          // rtr_stream_probe variant (experiments)
     int opt_cull = 0;           // per-chunk frustum culling in T1
     int opt_auto_reorder = 2;   // Morton-sort a cloud right after upload / generation: 0 never, 1 always, 2 when its
@@ -575,7 +575,7 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
         return RTR_OK;
     }
     if (!strcmp(key, "phases")) {  // T1: wave groups that start at different places of the cloud (k_project_bin)
-        NEED(c, value >= 1 && value <= 65535, "phases must be in 1..65535");
+        NEED(c, value >= 0 && value <= 65535, "phases must be in 0..65535 (0: automatic)");
         c->opt_phases = value;
         c->list_valid = false;
         return RTR_OK;

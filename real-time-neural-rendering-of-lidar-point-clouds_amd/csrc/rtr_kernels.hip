@@ -830,7 +830,14 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
     // 16 chunks to each wave instead cost +50 us), and every wave still samples the whole cloud.
     const uint32_t nchunks = (n4 + 63u) / 64u, NW = gridDim.x * (kBlock / 64), wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t R = (nchunks + NW - 1u) / NW;
-    const uint32_t G = cblock < 1u ? 1u : (cblock > gridDim.x ? gridDim.x : cblock);
+    // cblock = 0 (the default): one group, unless the PREVIOUS frame of this tile store had more than a quarter
+    // of the cloud inside the frustum (its entry count is still in the header; T1's epilogue rewrites it when
+    // every workgroup is past this line).  Then the claims, not the stream, bound the kernel -- ~390 k wave
+    // claims on the dozen stream counters of a distant overview -- and 16 groups that sit in different parts
+    // of the cloud, i.e. in different tiles, spread them: 1.45 -> 0.87 ms for 1e8 points inside 100 x 40
+    // pixels, against +10 us on an ordinary view, which therefore keeps the single dense streaming front.
+    const uint32_t auto_groups = ts_hdr(S)[kHdrEntries] > n4 ? 16u : 1u;
+    const uint32_t G = cblock < 1u ? auto_groups : (cblock > gridDim.x ? gridDim.x : cblock);
     const uint32_t phase = (uint32_t)((uint64_t)((blockIdx.x * G) / gridDim.x) * R / G);
     auto chunk_of = [&](uint32_t q) -> uint32_t {  // q-th chunk of this wave, q < R (>= nchunks: none)
         uint32_t r = q + phase;
