@@ -297,8 +297,10 @@ rtr::Proj make_proj(const float P[16]) {
 }
 
 rtr::Cloud cloud_of(const rtr_ctx *c) {
-    // (a chunk of 256 points as large as a quarter of the cloud: consecutive points are unrelated)
-    return rtr::Cloud{c->x, c->y, c->z, c->rgba, c->n, c->opt_grid, (!c->reordered && c->order_ratio > 0.25f) ? 1 : 0,
+    // (a chunk of 256 points spanning more than half of the cloud: consecutive points are unrelated.  A hash-ordered
+    // cloud measures ~1.0; the reference loader's 0.25 m blocks in hash-map order, unordered inside, measure 0.28 for a
+    // 10 m room and must keep the wave-level claim groups: 0.33 ms instead of 0.66 ms per frame without them)
+    return rtr::Cloud{c->x, c->y, c->z, c->rgba, c->n, c->opt_grid, (!c->reordered && c->order_ratio > 0.5f) ? 1 : 0,
                       rtr::PackedXyz{c->pk_hdr, c->pk_planes}};
 }
 

@@ -797,7 +797,7 @@ __device__ __forceinline__ void unpack_chunk(const ChunkRaw &c, uint32_t widths,
 // < 3e-7 x that magnitude, so no point the exact arithmetic would keep is ever skipped).
 // Only spatially coherent point orders have tight chunk boxes (rtr_reorder_points).
 // GROUPS = false: a cloud whose consecutive points are unrelated (measured at upload: its 256-point chunks
-// span a quarter of the cloud or more) and that the caller asked not to sort -- every quad's points fall
+// span more than half of the cloud) and that the caller asked not to sort -- every quad's points fall
 // into as many tiles as it has points, so the grouping rounds are skipped and every point claims per lane.
 // PACKED: the coordinates come from the PackedXyz form (x4 = its headers, y4 = its planes, z4 unused): 6-9
 // bytes per point instead of 12 for spatially ordered clouds.  A chunk's header is requested one iteration
