@@ -954,19 +954,26 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
                 rank[k] = atomicAdd(fill + ((size_t)st[k] << S.fill_shift), 1u);
                 grp[k] = kMaxGroups;
             }
-        uint32_t base[kMaxGroups];
+        // (only the ng groups that exist -- usually two or three of twelve -- cost a readlane and four selects)
+        uint32_t bsel[4] = {0u, 0u, 0u, 0u};
+        auto select_base = [&](auto self, auto it_tag) -> void {  // nested wave-uniform tests: it < ng, statically indexed
+            constexpr int it = decltype(it_tag)::value;
+            if constexpr (it < kMaxGroups) {
+                if (it < ng) {
+                    const uint32_t b_it = (uint32_t)__builtin_amdgcn_readlane((int)claim[it], it);
 #pragma unroll
-        for (int it = 0; it < kMaxGroups; ++it)
-            base[it] = it < ng ? (uint32_t)__builtin_amdgcn_readlane((int)claim[it], it) : 0u;
+                    for (int k = 0; k < 4; ++k) bsel[k] = grp[k] == it ? b_it : bsel[k];
+                    self(self, std::integral_constant<int, it + 1>{});
+                }
+            }
+        };
+        select_base(select_base, std::integral_constant<int, 0>{});
         const uint32_t cs[4] = {col.x, col.y, col.z, col.w};
         uint32_t v[4];
         bool dyn = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            uint32_t b = 0;
-#pragma unroll
-            for (int it = 0; it < kMaxGroups; ++it) b = grp[k] == it ? base[it] : b;
-            v[k] = b + rank[k];
+            v[k] = bsel[k] + rank[k];
             dyn = dyn || (in[k] && v[k] >= kS0);
         }
         if (RTR_XP(4)) return;
