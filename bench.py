@@ -69,6 +69,9 @@ def parse():
                     help="bracket every phase with HIP events (default: only the dominant streaming kernel)")
     ap.add_argument("--overlap", type=int, default=0, choices=[0, 1],
                     help="N=1: library option \"overlap\" (T1 of frame k+1 on a second stream beside the tail of frame k)")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
+                    help="measurement aid: rtr_set_option(KEY, VALUE) on every context before the cloud is generated "
+                         "(e.g. pack=0, point_grid=1024); listed in config.options")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the separately reported legs (uniform_box, chunk culling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -202,6 +205,9 @@ def main():
                 pj = pkg.Projector(local_rank)
                 if auto_reorder is not None:
                     pj.set_option("auto_reorder", auto_reorder)
+                for kv in args.set:
+                    key, val = kv.split("=")
+                    pj.set_option(key, int(val))
                 pj.generate_synthetic(scene, SEEDS["C3"], self.lo, self.hi - self.lo, total)
                 pj.set_resolution(W, H)
                 if args.overlap and not multi:
@@ -496,6 +502,7 @@ def main():
                                       (" sharded %d ways" % world) if world > 1 else ""),
                        "points_total": total, "points_per_gpu": n_local, "scene": args.scene,
                        "resolution": [W, H], "prefilter": with_filter,
+                       **({"options": args.set} if args.set else {}),
                        "parallelism": (("point-shard x%d, hand-written peer-to-peer exchange over hipIpc-mapped buffers: "
                                         "MIN(depth), SUM(accum) + slice resolve, %d frames in flight" % (world, depth_k))
                                        if (exchange_info or {}).get("used") == "p2p" else
