@@ -247,8 +247,9 @@ int rtr_stream_probe(rtr_ctx *ctx, const float P[16]);
  * streaming point kernels (RTR_K_MIN_DEPTH, RTR_K_ACCUMULATE), i.e. two event records per
  * frame; on = 3: like 2 but only every 4th launch is bracketed (a bracket costs ~8 us of stream
  * time, 3 % of a frame); 0: off.  The tile-binned form's RTR_K_MIN_DEPTH launch carries its two
- * events in the dispatch itself (start / stop stamps of that kernel, nothing added to the stream).  rtr_timing_get synchronises and returns the accumulated device
- * time and the number of bracketed launches. */
+ * events in the dispatch itself (start / stop stamps of that kernel: no extra packets, but a timed
+ * dispatch still costs ~10 us of stream time).  rtr_timing_get synchronises and returns the
+ * accumulated device time and the number of bracketed launches. */
 int rtr_timing_enable(rtr_ctx *ctx, int on);
 /* Statistics of the last binned frame (mode 1; synchronises the stream): out[0] work items of the
  * tile kernel, [1] of them slices of split tiles, [2] in-frustum entries, [3] entries of the
