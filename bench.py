@@ -65,11 +65,12 @@ def parse():
     ap.add_argument("--force-exchange", action="store_true",
                     help="rehearsal on ONE GPU: run the N>1 code path (streams, RCCL collectives in a 1-rank "
                          "group, 2 frames in flight); the numbers are not a benchmark result")
-    ap.add_argument("--time-every", type=int, default=-1, choices=[-1, 0, 1, 4],
-                    help="bracket the dominant kernel on every frame (1), every 4th frame (4) or never (0: no roofline "
-                         "object; to measure what the bracketing itself costs).  Default: every 4th frame, every frame "
-                         "for runs of <= 32 steps.  A bracketed dispatch costs ~10 us of stream time (completion "
-                         "signal + time stamps): 0.228 ms per frame with every frame bracketed, 0.217 with every 4th")
+    ap.add_argument("--time-every", type=int, default=-1, choices=[-1, 0, 1, 2, 4],
+                    help="bracket the dominant kernel on every frame (1), every 2nd (2), every 4th frame (4) or never "
+                         "(0: no roofline object; to measure what the bracketing itself costs).  Default: every 4th "
+                         "frame, every 2nd for runs of <= 32 steps (so that a 20-step run still times 10 launches).  A "
+                         "bracketed dispatch costs ~10 us of stream time (completion signal + time stamps): 0.228 ms "
+                         "per frame with every frame bracketed, 0.217 with every 4th")
     ap.add_argument("--time-all-kernels", action="store_true",
                     help="bracket every phase with HIP events (default: only the dominant streaming kernel)")
     ap.add_argument("--overlap", type=int, default=0, choices=[0, 1],
@@ -141,7 +142,7 @@ def roofline_of(kern_ms, launches, n_local, traffic, every, stream_bpp=12.0):
                            "bound by instruction issue (rocprofv3 PMC: VALUBusy + SALUBusy ~ 90 %, DESIGN.md)")
                           if stream_bpp < 11.9 else "coordinates read as fp32 SoA (12 B/pt)",
             "how": "HIP events on the kernel's stream inside the timed region, " +
-                   ("every frame" if every == 1 else "every 4th frame") +
+                   {1: "every frame", 2: "every 2nd frame", 4: "every 4th frame"}.get(every, "?") +
                    "; in the tile-binned form the two events are the start / stop stamps of the kernel's own "
                    "dispatch (hipExtLaunchKernelGGL): no extra packets on the stream, but a bracketed dispatch still "
                    "costs ~10 us of stream time and reads ~5 % longer than in the rocprof trace"}
@@ -192,7 +193,7 @@ def main():
     W, H = args.width, args.height
     with_filter = not args.no_filter
     poses = [pkg.orbit_projection(k, W, H) for k in range(args.warmup + args.steps)]
-    every = args.time_every if args.time_every >= 0 else (1 if args.steps <= 32 else 4)
+    every = args.time_every if args.time_every >= 0 else (2 if args.steps <= 32 else 4)
     depth_k = args.pipeline if multi else args.frames_in_flight
 
     def all_ranks(ok):
@@ -250,7 +251,7 @@ def main():
                 self.render(rs, k, poses[k])
             self.sync()
             for pj in self.projs:
-                pj.timing_enable(1 if args.time_all_kernels else (2 if every == 1 else (3 if every == 4 else 0)))
+                pj.timing_enable(1 if args.time_all_kernels else {0: 0, 1: 2, 2: 4, 4: 3}[every])
                 pj.timing_reset()
             t0 = time.perf_counter()
             for k in range(steps):

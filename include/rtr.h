@@ -246,7 +246,7 @@ int rtr_stream_probe(rtr_ctx *ctx, const float P[16]);
 /* on = 1: every phase is bracketed by hipEvents on the context's stream; on = 2: only the
  * streaming point kernels (RTR_K_MIN_DEPTH, RTR_K_ACCUMULATE), i.e. two event records per
  * frame; on = 3: like 2 but only every 4th launch is bracketed (a bracket costs ~8 us of stream
- * time, 3 % of a frame); 0: off.  The tile-binned form's RTR_K_MIN_DEPTH launch carries its two
+ * time, 3 % of a frame), on = 4: every 2nd; 0: off.  The tile-binned form's RTR_K_MIN_DEPTH launch carries its two
  * events in the dispatch itself (start / stop stamps of that kernel: no extra packets, but a timed
  * dispatch still costs ~10 us of stream time).  rtr_timing_get synchronises and returns the
  * accumulated device time and the number of bracketed launches. */

@@ -311,7 +311,8 @@ struct Timed {  // brackets one phase with hipEvents on the stream it is launche
         : c(c_), k(k_), s(s_ ? s_ : c_->stream), in_dispatch(in_dispatch_) {
         if (!c->timing) return;
         if (c->timing >= 2 && k != RTR_K_MIN_DEPTH && k != RTR_K_ACCUMULATE) return;
-        if (c->timing == 3 && (c->timing_tick++ & 3u) != 0u) return;  // a bracket costs ~8 us of stream time
+        if (c->timing == 3 && (c->timing_tick++ & 3u) != 0u) return;  // a bracket costs ~8-10 us of stream time
+        if (c->timing == 4 && (c->timing_tick++ & 1u) != 0u) return;
         if (c->pool.empty()) {
             (void)hipEventCreate(&a); (void)hipEventCreate(&b);
         } else {
@@ -1379,7 +1380,7 @@ int rtr_timing_enable(rtr_ctx *c, int on) {
     if (!c) return RTR_ERR_INVALID;
     DevGuard g(c->device);
     (void)collect_timing(c);
-    c->timing = on < 0 ? 0 : (on > 3 ? 1 : on);
+    c->timing = on < 0 ? 0 : (on > 4 ? 1 : on);
     c->timing_tick = 0;
     return RTR_OK;
 }
