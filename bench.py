@@ -411,8 +411,8 @@ def main():
         # (0) the same frames with library option "overlap": the point stream of frame k+1 is queued on a second
         #     HIP stream and starts while the tile kernel / prefilter of frame k still run
         proj.set_option("overlap", 1)
-        m = min(args.steps, 50)
-        dtp, tp = S.timed_run(renderers, m, min(args.warmup, 5))
+        m = args.steps  # (the same poses as the headline run: T1 depends on the pose)
+        dtp, tp = S.timed_run(renderers, m, args.warmup)
         proj.set_option("overlap", 0)
         pipelined = {"what": "option overlap = 1: T1 of frame k+1 on a second stream beside the tail of frame k (two tile "
                              "stores); same frames, bit-identical output.  Not the headline: beside the tail the point "
@@ -428,7 +428,7 @@ def main():
         for k in range(min(args.warmup, 5)):
             proj.render(poses[k], with_filter)
         proj.synchronize()
-        m = min(args.steps, 50)
+        m = args.steps  # (the same poses as the headline run: T1 depends on the pose)
         t1 = time.perf_counter()
         for k in range(m):
             proj.render(poses[args.warmup + k], with_filter)
@@ -444,7 +444,7 @@ def main():
             S = None
             ubox = {"what": "uniform_box: 100 M points in hash order (consecutive points are unrelated): every wave takes "
                             "the exact path and claims stream positions per point"}
-            m = min(args.steps, 50)
+            m = args.steps  # (the same poses as the headline run: T1 depends on the pose)
             for key, policy in (("as_uploaded", 0), ("default_upload_policy", None)):
                 U = Setup(args.points, "uniform_box", auto_reorder=policy)
                 t_up = None
@@ -453,7 +453,7 @@ def main():
                     U.projs[0].generate_synthetic("uniform_box", SEEDS["C3"], 0, args.points, args.points)
                     U.projs[0].synchronize()
                     t_up = time.perf_counter() - t0
-                dtu, tu = U.timed_run(U.renderers("allreduce"), m, min(args.warmup, 5))
+                dtu, tu = U.timed_run(U.renderers("allreduce"), m, args.warmup)
                 ku = kernel_table(tu)
                 req, two = frame_bytes(args.points, W, H, with_filter)
                 ubox[key] = {"value": args.points * m / dtu / 1e6, "unit": "Mpoints/s", "ms_per_step": dtu / m * 1e3,
