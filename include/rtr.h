@@ -211,7 +211,9 @@ int rtr_p2p_close(rtr_ctx *ctx);
 int rtr_p2p_min_depth(rtr_ctx *ctx);
 int rtr_p2p_sum_resolve(rtr_ctx *ctx);
 /* The whole sharded frame in one call: rtr_clear, rtr_min_depth_pass, rtr_p2p_min_depth,
- * rtr_accumulate_pass, rtr_p2p_sum_resolve and, if with_filter, rtr_filter.  Afterwards RTR_BUF_DEPTH,
+ * rtr_accumulate_pass, rtr_p2p_sum_resolve and, if with_filter, rtr_filter -- trimmed in the tile-binned form
+ * to eight launches (no clear, no slice reduction of the depth: one barrier, then the accumulate launch takes
+ * the MIN over the occupying ranks' depth tiles itself; no gathers).  Afterwards RTR_BUF_DEPTH,
  * RTR_BUF_IMAGE (and the prefilter's outputs) hold the GLOBAL frame on every rank; RTR_BUF_ACCUM holds
  * this rank's partial sums, and in the tile-binned form only under the screen tiles that contain
  * points of this rank (the peers read nothing else: tiles without local points are not written). */

@@ -89,6 +89,8 @@ struct rtr_ctx {
         uint8_t *ximg = nullptr;          // [3 * npix] resolved image; same (the prefilter rewrites RTR_BUF_IMAGE in place)
         uint32_t *flags = nullptr;        // [RTR_P2P_MAX_RANKS] uncached: barrier counters written by the peers
         uint32_t *occ = nullptr;          // [128] one bit per screen tile: this rank's frame has entries there
+        uint32_t *occ_all = nullptr;      // [kMaxPeers * 128] every rank's bitmap, gathered by the first barrier of a frame
+        bool depth_peers = false;         // rtr_p2p_render: the accumulate launch takes the MIN over the peers' depth itself
         bool occ_current = false;         // occ was computed from the bins that are valid now
         bool occ_from_scan = false;       // ... by the epilogue of this frame's T1 (no separate launch)
         bool whole_frame = false;         // inside rtr_p2p_render: the tile launches are the only writers of depth /
@@ -169,6 +171,7 @@ void p2p_release(rtr_ctx *c) {  // the peers' mappings and this rank's exchange 
     dfree(q.ximg);
     dfree(q.flags);
     dfree(q.occ);
+    dfree(q.occ_all);
     q.open = false;
     q.world = 0;
     q.seq = 0;
@@ -1011,14 +1014,18 @@ int rtr_accumulate_pass(rtr_ctx *c, const float P[16]) {
             pyr.part_max = c->part_max;
         }
         rtr::Sliced dsl{};
-        if (c->p2p.whole_frame && c->p2p.depth_sliced) {
+        if (c->p2p.whole_frame && c->p2p.depth_peers) {  // MIN over the occupying ranks' local depth, tile by tile
+            dsl.src = c->p2p.depth;
+            dsl.peers = c->p2p.world;
+            dsl.occ_all = c->p2p.occ_all;
+        } else if (c->p2p.whole_frame && c->p2p.depth_sliced) {
             dsl.src = c->p2p.reduced;
             dsl.chunk = p2p_slice(c).chunk;
         }
-        c->p2p.depth_sliced = false;
+        c->p2p.depth_sliced = c->p2p.depth_peers = false;
         Timed t(c, RTR_K_TILE);
         rtr::launch_tile(c->stream, 2, c->W, c->H, c->F().store, c->prm.depth_window, c->depth, c->acc, c->img,
-                         c->p2p.whole_frame ? 6 : 0, pyr.enable ? &pyr : nullptr, dsl.chunk ? &dsl : nullptr);
+                         c->p2p.whole_frame ? 6 : 0, pyr.enable ? &pyr : nullptr, (dsl.chunk || dsl.peers) ? &dsl : nullptr);
         mark_consumed(c);
     } else {
         Timed t(c, RTR_K_ACCUMULATE);
@@ -1148,6 +1155,7 @@ static int p2p_alloc(rtr_ctx *c) {  // this rank's exchange buffers (per resolut
     if (!q.red) HIP_TRY(c, hipMalloc((void **)&q.red, ((npix + 3) & ~(size_t)3) * sizeof(uint32_t)));
     if (!q.ximg) HIP_TRY(c, hipMalloc((void **)&q.ximg, (npix * 3 + 15) & ~(size_t)15));
     if (!q.occ) HIP_TRY(c, hipMalloc((void **)&q.occ, rtr::kP2POccBytes));
+    if (!q.occ_all) HIP_TRY(c, hipMalloc((void **)&q.occ_all, (size_t)rtr::kMaxPeers * rtr::kP2POccBytes));
     if (!q.flags) {
         HIP_TRY(c, hipExtMallocWithFlags((void **)&q.flags, 4096, hipDeviceMallocUncached));
         HIP_TRY(c, hipMemsetAsync(q.flags, 0, 4096, c->stream));
@@ -1304,7 +1312,22 @@ int rtr_p2p_render(rtr_ctx *c, const float P[16], int with_filter) {
     q.pyramid_done = q.whole_frame && with_filter && c->prm.levels == 4;
     int rc = q.whole_frame ? RTR_OK : rtr_clear(c);
     if (!rc) rc = rtr_min_depth_pass(c, P);
-    if (!rc) rc = rtr_p2p_min_depth(c);
+    if (!rc && q.whole_frame && c->list_valid && q.occ_from_scan) {
+        // Tile-binned frame: ONE barrier (every rank's min pass and occupancy bitmap are complete; the same
+        // launch gathers the bitmaps), then the accumulate launch takes the MIN over the occupying ranks' local
+        // depth tile by tile -- no slice reduction, no second barrier (the barrier in front of the colour
+        // exchange is what tells a rank that nobody reads its depth buffer any more).
+        DevGuard g(c->device);
+        q.occ_current = true;
+        q.acc_from_bins = false;
+        const unsigned long long ticks = 100000ull * (unsigned long long)c->opt_p2p_timeout_ms;
+        rtr::launch_p2p_sync_gather(c->stream, q.flags, q.flags_of, q.rank, q.world, ++q.seq, q.status_dev, ticks, q.occ_of,
+                                    q.occ_all);
+        q.depth_peers = true;
+        rc = launch_check(c, "p2p barrier");
+    } else if (!rc) {
+        rc = rtr_p2p_min_depth(c);
+    }
     if (!rc) rc = rtr_accumulate_pass(c, P);
     if (!rc) rc = rtr_p2p_sum_resolve(c);
     const int parts = q.pyramid_done ? rtr::tile_count(c->W, c->H) : 0;
@@ -1313,7 +1336,7 @@ int rtr_p2p_render(rtr_ctx *c, const float P[16], int with_filter) {
         isl.src = q.image;
         isl.chunk = p2p_slice(c).chunk;
     }
-    q.whole_frame = q.pyramid_done = q.depth_sliced = q.image_sliced = false;
+    q.whole_frame = q.pyramid_done = q.depth_sliced = q.depth_peers = q.image_sliced = false;
     if (!rc && with_filter) rc = filter_impl(c, parts, isl.chunk ? &isl : nullptr);
     return rc;
 }

@@ -52,9 +52,14 @@ struct PeerSet {
 // A frame-sized buffer that still lies in per-rank slices of `chunk` elements (the reduced depth /
 // the resolved image right after the slice kernels): element i is read from src.p[i / chunk].
 // chunk == 0: not sliced, use the local buffer.
+// peers > 0 (accumulate pass of a sharded whole frame): src.p[r] is rank r's LOCAL depth buffer and the
+// element is the MIN over the ranks whose bit for the tile is set in occ_all[r * 128 + (tile >> 5)] (every
+// rank's occupancy bitmap, gathered into local memory by the barrier launch).
 struct Sliced {
     PeerSet src;
     size_t chunk;
+    const uint32_t *occ_all;
+    int peers;
 };
 struct TilePyr {  // F1 folded into T4 (whole-frame calls with the default 4 levels)
     FilterLevels L;
@@ -183,6 +188,9 @@ void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, u
                    float strength, float thr, int pyramid_parts, const Sliced *img_slices = nullptr);
 void launch_p2p_sync(hipStream_t s, uint32_t *my_flags, const PeerSet &peer_flags, int rank, int world, uint32_t seq,
                      uint32_t *status, unsigned long long timeout_ticks);
+// the same barrier + every rank's occupancy bitmap gathered into occ_all[world * 128] (local memory)
+void launch_p2p_sync_gather(hipStream_t s, uint32_t *my_flags, const PeerSet &peer_flags, int rank, int world, uint32_t seq,
+                            uint32_t *status, unsigned long long timeout_ticks, const PeerSet &occ, uint32_t *occ_all);
 constexpr int kP2POccBytes = 512;  // occupancy bitmap: one bit per screen tile (<= 4096)
 void launch_p2p_occupancy(hipStream_t s, const uint32_t *tile_cnt, int W, int H, uint32_t *occ);
 void launch_p2p_depth_reduce(hipStream_t s, const PeerSet &depth, const PeerSet &occ, uint32_t *red, size_t first,

@@ -1416,13 +1416,28 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
                 }
             }
         }
+        uint32_t occ_mask = 0;  // MODE 2, sharded whole frame: the ranks that have points in this tile
+        if (MODE == 2 && dsl.peers)
+            for (int r = 0; r < dsl.peers; ++r)
+                occ_mask |= ((dsl.occ_all[r * 128 + ((tile & 4095) >> 5)] >> (tile & 31)) & 1u) << r;
         // depth tile
         for (int p = tid; p < tpix; p += T) {
             if (MODE >= 2) {
                 int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
                 if (x < W && y < H) {
                     const size_t gp = (size_t)y * W + x;
-                    if (dsl.chunk) {  // sharded frame: the global minimum still lies in the ranks' reduced slices
+                    if (MODE == 2 && dsl.peers) {  // sharded frame: MIN over the local depth of the ranks that occupy this tile
+                        uint32_t v = RTR_EMPTY;
+                        for (int r = 0; r < dsl.peers; ++r)
+                            if ((occ_mask >> r) & 1u) {
+                                const uint32_t u = static_cast<const uint32_t *>(dsl.src.p[r])[gp];
+                                v = u < v ? u : v;
+                            }
+                        s_depth[p] = v;
+                        // (a peer may be reading this word right now: it sees this rank's minimum or the global one,
+                        // and takes the MIN over all ranks either way)
+                        if (sub == 0) depth[gp] = v;  // ... and this launch is what completes RTR_BUF_DEPTH
+                    } else if (dsl.chunk) {  // sharded frame: the global minimum lies in the ranks' reduced slices
                         const uint32_t v = static_cast<const uint32_t *>(dsl.src.p[gp / dsl.chunk])[gp];
                         s_depth[p] = v;
                         if (sub == 0) depth[gp] = v;  // ... and this launch is what completes RTR_BUF_DEPTH
@@ -1946,6 +1961,7 @@ void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, floa
     TileGeom g = tile_geom(W, H);
     Sliced nosl{};
     nosl.chunk = 0;
+    nosl.peers = 0;
     size_t tpix = (size_t)32 << g.tw_shift;
     size_t lds = (mode == 1 ? tpix : 5 * tpix) * sizeof(uint32_t) + ((mode == 0 || mode == 3) ? 3 * tpix : 0);
     TilePyr none{};
@@ -2546,6 +2562,31 @@ __global__ void k_p2p_sync(uint32_t *__restrict__ my_flags, PeerSet peer_flags, 
     }
 }
 
+// The same barrier, and behind it every rank's occupancy bitmap copied into local memory (occ_all[r * words
+// + w]): the accumulate pass of a sharded frame then knows which peers to read for each of its tiles without
+// a remote round trip per workgroup.
+__global__ void k_p2p_sync_gather(uint32_t *__restrict__ my_flags, PeerSet peer_flags, int rank, int world, uint32_t seq,
+                                  uint32_t *__restrict__ status, unsigned long long timeout_ticks, PeerSet occ, int words,
+                                  uint32_t *__restrict__ occ_all) {
+    const int t = threadIdx.x;
+    if (t < world && t != rank) {
+        __hip_atomic_store(static_cast<uint32_t *>(peer_flags.p[t]) + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(my_flags + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            if (wall_clock64() - t0 > timeout_ticks) {
+                *reinterpret_cast<volatile uint32_t *>(status) = 1u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (one wave: every lane is past its peer's flag here)
+    __builtin_amdgcn_wave_barrier();
+    for (int i = t; i < world * words; i += 64)
+        occ_all[i] = __hip_atomic_load(static_cast<const uint32_t *>(occ.p[i / words]) + i % words, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Tile occupancy: a rank whose binned frame has no entry in a screen tile has left that tile of
 // its depth buffer at the sentinel and of its accumulators at zero (rtr_clear), so nobody needs
 // to pull it.  Point slices of a spatially ordered cloud are spatially compact, hence most tiles
@@ -2666,6 +2707,11 @@ __global__ __launch_bounds__(kBlock) void k_p2p_acc_resolve(PeerSet acc, PeerSet
 void launch_p2p_sync(hipStream_t s, uint32_t *my_flags, const PeerSet &peer_flags, int rank, int world, uint32_t seq,
                      uint32_t *status, unsigned long long timeout_ticks) {
     hipLaunchKernelGGL(k_p2p_sync, dim3(1), dim3(64), 0, s, my_flags, peer_flags, rank, world, seq, status, timeout_ticks);
+}
+void launch_p2p_sync_gather(hipStream_t s, uint32_t *my_flags, const PeerSet &peer_flags, int rank, int world, uint32_t seq,
+                            uint32_t *status, unsigned long long timeout_ticks, const PeerSet &occ, uint32_t *occ_all) {
+    hipLaunchKernelGGL(k_p2p_sync_gather, dim3(1), dim3(64), 0, s, my_flags, peer_flags, rank, world, seq, status,
+                       timeout_ticks, occ, 128, occ_all);
 }
 // tile_cnt == NULL: every tile counts as occupied (the frame did not come from the bins)
 void launch_p2p_occupancy(hipStream_t s, const uint32_t *tile_cnt, int W, int H, uint32_t *occ) {
