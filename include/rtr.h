@@ -6,7 +6,7 @@
  * C ABI / FFI of its own -- its boundary is a C++ class dragging in OpenCV, glm
  * and libtorch -- so these entry points are what a binding of that class would
  * need: plain pointers and sizes, no torch / OpenCV / glm types.  The header-
- * compatible C++ facade (csrc/project_cloud_facade.hpp) and the Python mirror are
+ * compatible C++ facade (include/rtr_project_cloud.hpp) and the Python mirror are
  * thin wrappers over exactly these calls; INTEGRATION.md shows the reference-side
  * binding.
  *
@@ -41,7 +41,10 @@ typedef enum {
     RTR_ERR_INVALID = -1,   /* bad argument / call order                         */
     RTR_ERR_HIP = -2,       /* a HIP runtime call failed (text in last_error)    */
     RTR_ERR_NO_OUTPUT = -3, /* both host outputs NULL (project_cloud.cu:270-273) */
-    RTR_ERR_UNSUPPORTED = -4/* e.g. filter with W % 2^levels != 0 (quirk Q3)     */
+    RTR_ERR_UNSUPPORTED = -4,/* e.g. filter with W % 2^levels != 0 (quirk Q3)    */
+    RTR_ERR_INTERNAL = -5   /* the tile store dropped entries: frames rendered since the last synchronising call
+                               are incomplete (returned by rtr_synchronize and by every call that copies results
+                               to the host; cannot happen unless the extent pool is mis-sized) */
 } rtr_status;
 
 /* Compile-time constants of the reference, made run-time parameters. */
@@ -115,6 +118,8 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          1.5 ms at 4, for +1 % on an ordinary view).
  *  "p2p_timeout_ms": how long a flag barrier of the peer-to-peer exchange (section 5b) waits for a rank
  *          that does not arrive before it flags the frame in rtr_p2p_status (default 2000).
+ *  "debug_dyn_cap": test aid -- caps the pool of dynamic stream extents at this many entries (-1 = off), so that a
+ *          heavy tile overflows it and the error path (RTR_ERR_INTERNAL) can be exercised.
  *  "xp": only in RTR_EXPERIMENT builds (make experiment): switches parts of the point kernel off for
  *          timing attribution -- frames are WRONG while it is non-zero; the shipped library rejects it.
  *  "probe_variant": measurement aid of tools/probe_variants.py (selects the rtr_stream_probe kernel). */
@@ -255,7 +260,9 @@ int rtr_stream_probe(rtr_ctx *ctx, const float P[16]);
 int rtr_timing_enable(rtr_ctx *ctx, int on);
 /* Statistics of the last binned frame (mode 1; synchronises the stream): out[0] work items of the
  * tile kernel, [1] of them slices of split tiles, [2] in-frustum entries, [3] entries of the
- * heaviest tile, [4] slice size used, [5] error bits (0 = none), [6] split tiles, [7] reserved. */
+ * heaviest tile, [4] slice size used, [5] tile-store error bits of THAT frame (0 = none; 1 = an extent never
+ * appeared, 2 = the extent pool overflowed: entries were dropped), [6] split tiles, [7] 256-point chunks with
+ * at least one in-frustum point (each loads 1 KiB of colours). */
 int rtr_frame_stats(rtr_ctx *ctx, uint32_t out[8]);
 int rtr_timing_reset(rtr_ctx *ctx);
 int rtr_timing_get(rtr_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);

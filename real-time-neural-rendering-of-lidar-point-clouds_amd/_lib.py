@@ -25,7 +25,7 @@ SYMBOLS = [
     "rtr_p2p_render", "rtr_frame_stats", "rtr_get_option",
 ]
 
-RTR_OK, RTR_ERR_INVALID, RTR_ERR_HIP, RTR_ERR_NO_OUTPUT, RTR_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+RTR_OK, RTR_ERR_INVALID, RTR_ERR_HIP, RTR_ERR_NO_OUTPUT, RTR_ERR_UNSUPPORTED, RTR_ERR_INTERNAL = 0, -1, -2, -3, -4, -5
 BUF_DEPTH, BUF_ACCUM, BUF_IMAGE, BUF_TENSOR, BUF_MASK, BUF_MINMAX = range(6)
 K_CLEAR, K_MIN_DEPTH, K_ACCUMULATE, K_RESOLVE, K_FILTER, K_PROBE, K_TILE, K_BIN = range(8)
 P2P_HANDLES_BYTES = 6 * 64  # sizeof(rtr_p2p_handles)

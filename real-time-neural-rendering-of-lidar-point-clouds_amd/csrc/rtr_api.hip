@@ -73,6 +73,9 @@ struct rtr_ctx {
     int opt_slice = 16384;           // ... into slices of at least this many entries
     int opt_p2p_timeout_ms = 2000;   // peer-to-peer flag barriers give up after this long (option "p2p_timeout_ms")
     int opt_fill_shift = 4;          // stream counters 2^4 words = 64 B apart (see "fill_shift")
+    int opt_debug_dyn_cap = -1;      // test aid: cap the dynamic extent pool at this many entries (-1: off)
+    uint32_t *err_host = nullptr;    // mapped host word: tile-store error bits of frames since it was last read
+    uint32_t *err_dev = nullptr;     // ... as the device sees it (StoreConsts::err_host)
     int opt_xp = 0;                  // RTR_EXPERIMENT builds only (tools/kbench.py)
     int opt_phases = 0;         // T1: phase groups of the grid stride (option "phases", see k_project_bin); 0 = automatic
     int opt_probe = 0;          // rtr_stream_probe variant (experiments)
@@ -253,6 +256,8 @@ int ensure_tiles(rtr_ctx *c, hipStream_t s) {
     rtr::StoreConsts want{};
     want.depth = c->depth; want.acc = c->acc; want.occ = c->p2p.open ? c->p2p.occ : nullptr;
     want.dyn = f.dyn; want.dyn_cap = f.dyn_cap;
+    if (c->opt_debug_dyn_cap >= 0 && (uint64_t)c->opt_debug_dyn_cap < want.dyn_cap) want.dyn_cap = (uint64_t)c->opt_debug_dyn_cap;
+    want.err_host = c->err_dev;
     want.heavy = c->opt_heavy > 0 ? (uint32_t)c->opt_heavy : 0xFFFFFFFFu;
     want.slice = (uint32_t)c->opt_slice;
     if (memcmp(&want, &f.consts, sizeof want) != 0) {
@@ -338,6 +343,18 @@ hipError_t sync_streams(rtr_ctx *c) {
         if (e != hipSuccess) return e;
     }
     return hipStreamSynchronize(c->stream);
+}
+
+// Tile-store errors (entries dropped by T1: an extent that never appeared, an exhausted extent pool) reach the
+// host through a mapped word that T1's epilogue writes; every call that has just synchronised reports and
+// clears it -- a wrong frame is never returned as RTR_OK.
+int check_store_error(rtr_ctx *c) {
+    if (!c->err_host) return RTR_OK;
+    const uint32_t e = __atomic_exchange_n(c->err_host, 0u, __ATOMIC_ACQUIRE);
+    if (e == 0u) return RTR_OK;
+    return fail(c, RTR_ERR_INTERNAL, "tile store error 0x%x: %s%s-- entries were dropped, frames rendered since the last "
+                "synchronising call are incomplete", e, (e & 1u) ? "a stream extent never appeared " : "",
+                (e & 2u) ? "the dynamic extent pool overflowed " : "");
 }
 
 // after the last reader of the active list / bin set has been queued on the tail stream
@@ -440,8 +457,17 @@ int rtr_create(rtr_ctx **out, int device) {
     }
     c->stream = c->own_stream;
     e = hipMalloc((void **)&c->minmax, 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->err_host, sizeof(uint32_t), hipHostMallocMapped);
+    if (e == hipSuccess) {
+        *c->err_host = 0u;
+        void *d = nullptr;
+        e = hipHostGetDevicePointer(&d, c->err_host, 0);
+        c->err_dev = static_cast<uint32_t *>(d);
+    }
     if (e != hipSuccess) {
         int rc = fail(nullptr, RTR_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+        if (c->minmax) (void)hipFree(c->minmax);
+        if (c->err_host) (void)hipHostFree(c->err_host);
         (void)hipStreamDestroy(c->own_stream);
         delete c;
         return rc;
@@ -461,6 +487,7 @@ int rtr_destroy(rtr_ctx *c) {
     free_cloud(c);
     dfree(c->minmax);
     if (c->p2p.status_host) (void)hipHostFree(c->p2p.status_host);
+    if (c->err_host) (void)hipHostFree(c->err_host);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return RTR_OK;
@@ -575,6 +602,12 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
         c->list_valid = false;
         return RTR_OK;
     }
+    if (!strcmp(key, "debug_dyn_cap")) {  // test aid: a pool this small makes heavy tiles overflow it (error code 2)
+        NEED(c, value >= -1, "debug_dyn_cap must be >= -1 (-1: off)");
+        c->opt_debug_dyn_cap = value;
+        c->list_valid = false;
+        return RTR_OK;
+    }
     if (!strcmp(key, "p2p_timeout_ms")) {
         NEED(c, value >= 1 && value <= 60000, "p2p_timeout_ms must be in 1..60000");
         c->opt_p2p_timeout_ms = value;
@@ -683,7 +716,7 @@ int rtr_synchronize(rtr_ctx *c) {
     if (!c) return RTR_ERR_INVALID;
     DevGuard g(c->device);
     HIP_TRY(c, sync_streams(c));
-    return RTR_OK;
+    return check_store_error(c);
 }
 
 // ---- cloud -------------------------------------------------------------------------
@@ -1136,7 +1169,7 @@ static int frame_to_host(rtr_ctx *c, const float P[16], uint8_t *host_img, float
     if (host_depth) HIP_TRY(c, hipMemcpyAsync(host_depth, c->depth, npix * 4, hipMemcpyDeviceToHost, c->stream));
     if (host_img) HIP_TRY(c, hipMemcpyAsync(host_img, c->img, npix * 3, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, sync_streams(c));
-    return RTR_OK;
+    return check_store_error(c);
 }
 
 int rtr_project(rtr_ctx *c, const float P[16], uint8_t *host_img, float *host_depth) {
@@ -1374,7 +1407,7 @@ int rtr_download_buffer(rtr_ctx *c, int which, void *host, size_t bytes) {
     DevGuard g(c->device);
     HIP_TRY(c, hipMemcpyAsync(host, p, b, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, sync_streams(c));
-    return RTR_OK;
+    return check_store_error(c);
 }
 
 // ---- measurement -------------------------------------------------------------------

@@ -88,6 +88,7 @@ struct StoreConsts {  // rarely needed, rarely changing: lives in the store's he
     uint64_t *dyn;                // [dyn_cap] pool of the dynamic extents
     uint64_t dyn_cap;
     uint32_t heavy, slice;        // split tiles with more entries than `heavy` into slices of >= `slice`
+    uint32_t *err_host;           // mapped host word: T1's epilogue ORs a frame's tile-store error code into it
 };
 // meta, in 32-bit words:
 //   fill[nst << kFillShiftMax]  stream length while T1 runs; zero between frames
@@ -101,21 +102,26 @@ struct StoreConsts {  // rarely needed, rarely changing: lives in the store's he
 //   perm[nt]       tile -> record position: tiles that held more than twice the mean entry count in
 //                  the PREVIOUS frame first (written by an extra workgroup of the tile launch)
 //   hdr[32]        kHdr* below; hdr[kHdrConsts ..] = StoreConsts
-//   ticket[2]      T1 workgroups that have finished
+//   ticket[2]      (u64) low word: T1 workgroups that have finished; high word: 256-point chunks whose colours were loaded
 //   pool_next[2]   (u64) entries of `dyn` handed out in this frame
 //   dir[nst * kDirK * 2]  (u64) extent base << 24 | frame stamp (valid iff stamp == seq)
-__host__ __device__ inline size_t ts_even(size_t x) { return (x + 1) & ~(size_t)1; }
-__host__ __device__ inline size_t ts_off_count(int nst, int nt) { return ts_even((size_t)nst << kFillShiftMax); }
-__host__ __device__ inline size_t ts_off_tile_cnt(int nst, int nt) { return ts_off_count(nst, nt) + ts_even((size_t)nst); }
-__host__ __device__ inline size_t ts_off_hctr(int nst, int nt) { return ts_off_tile_cnt(nst, nt) + ts_even((size_t)nt); }
-__host__ __device__ inline size_t ts_off_items(int nst, int nt) { return ts_off_hctr(nst, nt) + ts_even((size_t)nt); }
-__host__ __device__ inline size_t ts_off_hdr(int nst, int nt) { return ts_off_items(nst, nt) + ((size_t)2 * nt + kHeavyExtra + 1) * 8; }
-__host__ __device__ inline size_t ts_off_ticket(int nst, int nt) { return ts_off_hdr(nst, nt) + 32; }
-__host__ __device__ inline size_t ts_off_pool(int nst, int nt) { return ts_off_ticket(nst, nt) + 2; }
-__host__ __device__ inline size_t ts_off_dir(int nst, int nt) { return ts_off_pool(nst, nt) + 2; }
-__host__ __device__ inline size_t ts_off_perm(int nst, int nt) { return ts_off_dir(nst, nt) + (size_t)nst * kDirK * 2; }
-__host__ __device__ inline size_t ts_off_dbg(int nst, int nt) { return ts_off_perm(nst, nt) + ts_even((size_t)nt); }
-__host__ __device__ inline size_t ts_meta_words(int nst, int nt) { return ts_off_dbg(nst, nt) + 128; }  // 64 u64 time stamps (RTR_EXPERIMENT builds)
+// (every sub-array starts on a 16-byte boundary: the work list is read and written as uint4 records, the
+// ticket, the pool cursor and the directory as 8-byte words)
+__host__ __device__ constexpr size_t ts_align4(size_t x) { return (x + 3) & ~(size_t)3; }
+__host__ __device__ constexpr size_t ts_off_count(int nst, int nt) { return ts_align4((size_t)nst << kFillShiftMax); }
+__host__ __device__ constexpr size_t ts_off_tile_cnt(int nst, int nt) { return ts_off_count(nst, nt) + ts_align4((size_t)nst); }
+__host__ __device__ constexpr size_t ts_off_hctr(int nst, int nt) { return ts_off_tile_cnt(nst, nt) + ts_align4((size_t)nt); }
+__host__ __device__ constexpr size_t ts_off_items(int nst, int nt) { return ts_off_hctr(nst, nt) + ts_align4((size_t)nt); }
+__host__ __device__ constexpr size_t ts_off_hdr(int nst, int nt) { return ts_off_items(nst, nt) + ((size_t)2 * nt + kHeavyExtra + 1) * 8; }
+__host__ __device__ constexpr size_t ts_off_ticket(int nst, int nt) { return ts_off_hdr(nst, nt) + 32; }
+__host__ __device__ constexpr size_t ts_off_pool(int nst, int nt) { return ts_off_ticket(nst, nt) + 2; }
+__host__ __device__ constexpr size_t ts_off_dir(int nst, int nt) { return ts_off_pool(nst, nt) + 2; }
+__host__ __device__ constexpr size_t ts_off_perm(int nst, int nt) { return ts_off_dir(nst, nt) + (size_t)nst * kDirK * 2; }
+__host__ __device__ constexpr size_t ts_off_dbg(int nst, int nt) { return ts_off_perm(nst, nt) + ts_align4((size_t)nt); }
+__host__ __device__ constexpr size_t ts_meta_words(int nst, int nt) { return ts_off_dbg(nst, nt) + 128; }  // 64 u64 time stamps (RTR_EXPERIMENT builds)
+static_assert(ts_off_items(150, 75) % 4 == 0 && ts_off_hdr(150, 75) % 4 == 0 && ts_off_ticket(150, 75) % 2 == 0 &&
+              ts_off_pool(150, 75) % 2 == 0 && ts_off_dir(150, 75) % 2 == 0 && ts_off_dbg(150, 75) % 2 == 0,
+              "tile store sub-arrays: 16-byte records / 8-byte words must be aligned (320x240: nst = 150)");
 __host__ __device__ inline uint32_t *ts_fill(const TileStore &S) { return S.meta; }
 __host__ __device__ inline uint32_t *ts_count(const TileStore &S) { return S.meta + ts_off_count(S.nst, S.ntiles); }
 __host__ __device__ inline uint32_t *ts_tile_cnt(const TileStore &S) { return S.meta + ts_off_tile_cnt(S.nst, S.ntiles); }
@@ -134,8 +140,12 @@ __host__ __device__ inline unsigned long long *ts_dbg(const TileStore &S) {
 __host__ __device__ inline unsigned long long *ts_dir(const TileStore &S) {
     return reinterpret_cast<unsigned long long *>(S.meta + ts_off_dir(S.nst, S.ntiles));
 }
+// kHdrError: the tile-store error code of the LAST frame (0: none; 1: an extent never appeared, 2: the extent pool
+// overflowed -- entries were dropped), published by T1's epilogue from kHdrErrLive, which store_error() ORs into
+// while T1 runs; kHdrColourChunks: 256-point chunks with at least one in-frustum point (each loads 1 KiB of colours)
 enum { kHdrItems = 0, kHdrSplitItems = 1, kHdrEntries = 2, kHdrHeaviest = 3, kHdrSlice = 4, kHdrError = 5,
-       kHdrSplitTiles = 6, kHdrConsts = 8 };
+       kHdrSplitTiles = 6, kHdrColourChunks = 7, kHdrConsts = 8, kHdrErrLive = 24 };
+static_assert(kHdrConsts + sizeof(StoreConsts) / 4 <= kHdrErrLive, "StoreConsts overlaps the header words behind it");
 __host__ __device__ inline const StoreConsts *ts_consts(const TileStore &S) {
     return reinterpret_cast<const StoreConsts *>(ts_hdr(S) + kHdrConsts);
 }

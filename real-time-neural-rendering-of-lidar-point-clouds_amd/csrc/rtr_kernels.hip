@@ -404,7 +404,7 @@ __device__ __forceinline__ unsigned long long make_entry(uint32_t depth_bits, ui
     return ((unsigned long long)depth_bits << 33) | ((unsigned long long)pix9 << 24) | (unsigned long long)(colour & 0xFFFFFFu);
 }
 
-__device__ __forceinline__ void store_error(const TileStore &S, uint32_t code) { atomicOr(ts_hdr(S) + kHdrError, code); }
+__device__ __forceinline__ void store_error(const TileStore &S, uint32_t code) { atomicOr(ts_hdr(S) + kHdrErrLive, code); }
 
 // Stream position v >= kS0 of storage tile st lies in extent k, which holds [kS0 << (k-1), kS0 << k).
 // The lane that claimed an extent's FIRST position allocates it (one returning add on the pool
@@ -498,7 +498,7 @@ __device__ __forceinline__ int stream_tile(const TileGeom &g, int tx, int ty, in
 //   first), frame statistics, the occupancy bitmap of the peer-to-peer exchange, pool / ticket reset.
 // Only when some tile exceeds the split threshold are its slices laid out (scans) and, if asked for,
 // its pixels reset.
-__device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split) {
+__device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split, uint32_t colour_chunks) {
     const TileGeom g = tile_geom(W, H);
     uint32_t *const fill = ts_fill(S), *const tile_cnt = ts_tile_cnt(S);
     uint32_t *const hdr = ts_hdr(S), *const hctr = ts_hctr(S);
@@ -641,8 +641,18 @@ __device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split) 
         hdr[kHdrHeaviest] = mx;
         hdr[kHdrSlice] = slice;
         hdr[kHdrSplitTiles] = n_heavy;
+        hdr[kHdrColourChunks] = colour_chunks;
+        // the frame's tile-store error (entries were dropped: the frame is wrong) becomes the header's published
+        // word and reaches the host through mapped memory -- rtr_synchronize and the calls that copy results to
+        // the host report it; the live word starts the next frame at zero
+        const uint32_t err = __hip_atomic_load(hdr + kHdrErrLive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hdr[kHdrError] = err;
+        if (err) {
+            hdr[kHdrErrLive] = 0u;
+            if (sc.err_host) *(volatile gu32_t)sc.err_host = err;  // (plain store: the word lives in host memory; sticky until the host reads it)
+        }
         *ts_pool(S) = 0ull;
-        *ts_ticket(S) = 0u;
+        *reinterpret_cast<unsigned long long *>(ts_ticket(S)) = 0ull;
     }
     RTR_STAMP(S, 4);
     // Whole frames (and sharded frames whose tile launches are the only writers) never clear the frame
@@ -857,6 +867,7 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
             r.ry[k] = f_add(fmaf(P.m[6], zs[k], fmaf(P.m[5], ys[k], f_mul(P.m[4], xs[k]))), P.m[7]);
         }
     };
+    uint32_t n_colour = 0;  // chunks of this wave whose colours were loaded (frame statistics)
     auto do_quad = [&](uint32_t i, bool live, const Rows &r) {
         const float *rx = r.rx, *ry = r.ry, *rz = r.rz;
         // (the kernel is bound by instruction issue once the coordinates are packed: one max3 + max + compare
@@ -898,6 +909,7 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
             }
         }
         if ((pm[0] | pm[1] | pm[2] | pm[3]) == 0ull || RTR_XP(8)) return;
+        n_colour += 1u;  // (wave-uniform: a scalar register)
         // the lane's four colours in one 16-byte load, in flight together with the claims.  Unconditional
         // (and the claims below write variables that have no other definition): a value that merges with
         // another one at the end of a divergent block is waited for right there, which turned one round
@@ -1040,17 +1052,39 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
         fetch_hdr(0);
         fetch_planes();
         fetch_hdr(1);
+#ifdef RTR_EXPERIMENT
+        uint32_t xp_sink = 0;
+#endif
         for (uint32_t q = 0; q < R; ++q) {
             Rows r;
             const bool live_c = live;
             const uint32_t i_c = i;
             float4 X, Y, Z;
+#ifdef RTR_EXPERIMENT
+            if (RTR_XP(128)) {  // the stream alone: headers, planes, loop bookkeeping
+                xp_sink ^= raw.a[0].d[0] ^ raw.a[1].d[1] ^ raw.a[2].d[2] ^ raw.a[0].d[3] ^ raw.a[1].d[0] ^ raw.a[2].d[1];
+                fetch_planes();
+                fetch_hdr(q + 2);
+                continue;
+            }
+#endif
             unpack_chunk(raw, ww, bx, by, bz, X, Y, Z);
             project_rows(X, Y, Z, r);
             fetch_planes();
             fetch_hdr(q + 2);
+#ifdef RTR_EXPERIMENT
+            if (RTR_XP(256)) {  // ... + decode + the three matrix rows
+                xp_sink ^= __float_as_uint(r.rx[0]) ^ __float_as_uint(r.ry[1]) ^ __float_as_uint(r.rz[2]) ^ __float_as_uint(r.rx[3]) ^
+                           __float_as_uint(r.rz[0]) ^ __float_as_uint(r.ry[2]) ^ __float_as_uint(r.rx[1]) ^ __float_as_uint(r.rz[3]) ^
+                           __float_as_uint(r.ry[0]) ^ __float_as_uint(r.rx[2]) ^ __float_as_uint(r.rz[1]) ^ __float_as_uint(r.ry[3]);
+                continue;
+            }
+#endif
             do_quad(i_c, live_c, r);
         }
+#ifdef RTR_EXPERIMENT
+        if (xp_sink == 0x12345678u && live) fill[0] = 0u;  // practically never; keeps the work alive
+#endif
     } else if (!CULL) {
         // Software pipeline: the coordinates of the wave's NEXT quad are requested as soon as the current
         // ones have gone through the matrix rows, i.e. before the long part of an in-frustum quad (claims,
@@ -1144,18 +1178,30 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
     }
     // every claim of this workgroup has returned (its value was used); the workgroup that takes the
     // last ticket sees every stream length final
-    __shared__ uint32_t s_last;
+    // The ticket is the low word of a 64-bit counter whose high word sums the workgroups' colour-chunk counts
+    // (frame statistics: bench.py prices the kernel by the bytes it moves) -- one atomic per workgroup for both.
+    __shared__ uint32_t s_last, s_colour_total;
+    __shared__ uint32_t s_colour[kBlock / 64];
 #ifdef RTR_EXPERIMENT
     const unsigned long long t_done = wall_clock64();
 #endif
+    if (lane == 0) s_colour[threadIdx.x >> 6] = n_colour;
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(ts_ticket(S), 1u) == gridDim.x - 1u ? 1u : 0u;
+    if (threadIdx.x == 0) {
+        uint32_t mine = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) mine += s_colour[w];
+        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(ts_ticket(S)),
+                                                 1ull | ((unsigned long long)mine << 32));
+        s_last = (uint32_t)old == gridDim.x - 1u ? 1u : 0u;
+        s_colour_total = (uint32_t)(old >> 32) + mine;
+    }
     __syncthreads();
 #ifdef RTR_EXPERIMENT
     if (s_last && threadIdx.x == 0) ts_dbg(S)[0] = t_done;
 #endif
-    if (s_last && !RTR_XP(32)) bin_epilogue(S, W, H, clear_split);
-    if (s_last && RTR_XP(32) && threadIdx.x == 0) *ts_ticket(S) = 0u;  // (only together with xp 8: nothing was claimed)
+    if (s_last && !RTR_XP(32)) bin_epilogue(S, W, H, clear_split, s_colour_total);
+    if (s_last && RTR_XP(32) && threadIdx.x == 0) *reinterpret_cast<unsigned long long *>(ts_ticket(S)) = 0ull;  // (only together with xp 8: nothing was claimed)
 }
 
 // Option "overlap": T1 runs beside the previous frame's tail, which still reads and writes the frame buffers,
@@ -1183,7 +1229,7 @@ void launch_reset_split(hipStream_t s, int W, int H, const TileStore &S, uint32_
 
 // frames without points: the epilogue alone
 __global__ __launch_bounds__(kBlock) void k_bin_empty(int W, int H, TileStore S, int clear_split) {
-    bin_epilogue(S, W, H, clear_split);
+    bin_epilogue(S, W, H, clear_split, 0u);
 }
 
 __device__ __forceinline__ float min2(float a, float b) { return a < b ? a : b; }  // project_cloud.cu:46-49

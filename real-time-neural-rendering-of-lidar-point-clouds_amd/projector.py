@@ -223,11 +223,12 @@ class Projector:
     def frame_stats(self):
         """Statistics of the last binned frame (synchronises): work items of the tile kernel, how many of
         them are slices of split tiles, in-frustum entries, entries of the heaviest tile, slice size,
-        error bits (0 = none), split tiles."""
+        tile-store error bits of that frame (0 = none), split tiles, 256-point chunks with an in-frustum point
+        (each loads 1 KiB of colours)."""
         out = np.zeros(8, np.uint32)
         self._chk(self._lib.rtr_frame_stats(self._ctx, _vp(out)))
         return {"items": int(out[0]), "split_items": int(out[1]), "entries": int(out[2]), "heaviest_tile": int(out[3]),
-                "slice": int(out[4]), "errors": int(out[5]), "split_tiles": int(out[6])}
+                "slice": int(out[4]), "errors": int(out[5]), "split_tiles": int(out[6]), "colour_chunks": int(out[7])}
 
     def timing_enable(self, on=True):
         """True / 1: every phase, 2: only the streaming point kernels, 3: those on every 4th launch, False / 0: off."""
