@@ -126,21 +126,39 @@ def frame_bytes(n_local, W, H, with_filter):
     return required, two_pass
 
 
-def roofline_of(kern_ms, launches, n_local, traffic, every, stream_bpp=12.0):
-    """`achieved` is the contract's figure: ALGORITHMIC bytes (12 B/pt, SURVEY.md 8d: fp32 xyz) / launch time.
-    The resident cloud may be smaller than that (option "pack": lossless, 6-9 B/pt for ordered clouds), so the
-    bytes the kernel really streams and their share of the HBM peak are stated next to it -- `frac` can
-    exceed what HBM could deliver for 12 B/pt, `resident_stream_frac` cannot."""
-    achieved = 12.0 * n_local / (kern_ms * 1e-3) / 1e9  # GB/s: 12 B/pt streamed by the dominant kernel
-    resident = stream_bpp * n_local
+def moved_bytes_model(stream_bpp, n_local, stats):
+    """Bytes the point kernel moves per launch, from what it does: the resident coordinate stream (fp32 SoA 12 B/pt,
+    or the lossless packed form, headers included), 1 KiB of colours for every 256-point chunk that holds an
+    in-frustum point, 8 bytes written per in-frustum entry.  `stats` = frame statistics averaged over frames of the
+    timed poses (rtr_frame_stats: entries, colour chunks); None for the atomic form, which streams xyz only."""
+    b = stream_bpp * n_local
+    if stats:
+        b += 1024.0 * stats["colour_chunks"] + 8.0 * stats["entries"]
+    return b
+
+
+def roofline_of(kern_ms, launches, n_local, traffic, every, stream_bpp=12.0, stats=None, limiter=None):
+    """`achieved` = the bytes the dominant kernel MOVES per launch / its average launch time; `frac` = that over
+    the 8 TB/s HBM peak -- a roofline fraction, never above 1.  The bytes are the PMC traffic of the committed
+    profile when it was taken on exactly this workload (`bytes_source` "pmc"), else the model above ("model":
+    resident stream + colours + entries).  The contract's algorithmic figure (12 B/pt fp32 xyz) over
+    the same time is kept as `vs_fp32_stream`: with the lossless packed coordinates (6-9 B/pt) the kernel reads
+    fewer bytes than that, so this ratio may exceed 1 -- it is a speed-up over an ideal fp32 stream, not a
+    statement about HBM efficiency."""
+    t = kern_ms * 1e-3
+    model = moved_bytes_model(stream_bpp, n_local, stats)
+    moved, source = (float(traffic), "pmc") if traffic else (model, "model")
+    achieved = moved / t / 1e9
     return {"bound": "hbm", "kernel": "min_depth (k_project_bin: stream + append)", "achieved": achieved,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes_per_launch": 12.0 * n_local, "avg_launch_ms": kern_ms, "launches_timed": int(launches),
-            "resident_stream_bytes_per_point": stream_bpp, "resident_stream_bytes_per_launch": resident,
-            "resident_stream_frac": resident / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "bound_note": ("coordinates read from the lossless packed form: the kernel is no longer HBM-bound but "
-                           "bound by instruction issue (rocprofv3 PMC: VALUBusy + SALUBusy ~ 90 %, DESIGN.md)")
-                          if stream_bpp < 11.9 else "coordinates read as fp32 SoA (12 B/pt)",
+            "bytes_per_launch": moved, "bytes_source": source, "bytes_model": model,
+            "avg_launch_ms": kern_ms, "launches_timed": int(launches),
+            "resident_stream_bytes_per_point": stream_bpp,
+            "frame_stats": stats,
+            "algorithmic_bytes_per_launch": 12.0 * n_local,
+            "vs_fp32_stream": 12.0 * n_local / t / 1e9 / HBM_PEAK_GBS,
+            "limiter": limiter or ("not profiled on this workload; on the headline workload the SQ wait counters "
+                                   "(profiles/) say what the kernel waits for"),
             "how": "HIP events on the kernel's stream inside the timed region, " +
                    {1: "every frame", 2: "every 2nd frame", 4: "every 4th frame"}.get(every, "?") +
                    "; in the tile-binned form the two events are the start / stop stamps of the kernel's own "
@@ -148,18 +166,18 @@ def roofline_of(kern_ms, launches, n_local, traffic, every, stream_bpp=12.0):
                    "costs ~10 us of stream time and reads ~5 % longer than in the rocprof trace"}
 
 
-def measured_traffic(scene, n_local, W, H, with_filter):
-    """HBM bytes per launch of the dominant kernel from the committed PMC profile -- only when that
-    profile was taken on exactly this workload (else null: a constant is not a measurement)."""
+def measured_traffic(scene, n_local, W, H, with_filter, pack=1):
+    """(HBM bytes per launch of the dominant kernel, what limits it) from the committed PMC profile -- only when
+    that profile was taken on exactly this workload (else null: a constant is not a measurement)."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         for rec in json.load(open(tpath)).get("records", []):
-            if (rec.get("scene"), rec.get("points"), rec.get("width"), rec.get("height"), rec.get("prefilter")) == \
-                    (scene, n_local, W, H, with_filter) and rec.get("kernel") == "min_depth":
-                return rec.get("bytes_per_launch")
+            if (rec.get("scene"), rec.get("points"), rec.get("width"), rec.get("height"), rec.get("prefilter"),
+                    rec.get("pack", 1)) == (scene, n_local, W, H, with_filter, pack) and rec.get("kernel") == "min_depth":
+                return rec.get("bytes_per_launch"), rec.get("limiter")
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def main():
@@ -414,9 +432,125 @@ def main():
     def kernel_table(timing_):
         return {k: (ms / max(n, 1)) for k, (ms, n) in timing_.items() if n}
 
+    def sample_stats(pj, pose_list, filt):
+        """Frame statistics (in-frustum entries, chunks whose colours were loaded) of the point kernel, averaged over
+        a sample of the timed poses: what `roofline.bytes_model` is computed from.  Tile-binned form only."""
+        if not pj.get_option("mode") or not pose_list:
+            return None
+        ent = col = 0
+        sample = pose_list[::max(1, len(pose_list) // 25)]
+        for P in sample:
+            pj.render(P, filt)
+            st = pj.frame_stats()
+            if st["errors"]:
+                sys.exit("tile store error %d in a bench frame" % st["errors"])
+            ent, col = ent + st["entries"], col + st["colour_chunks"]
+        return {"entries": ent / len(sample), "colour_chunks": col / len(sample), "frames_sampled": len(sample)}
+
+    timed_poses = poses[args.warmup:args.warmup + args.steps]
+
     dt, timing, exchange_info = run_exchange_forms(S, renderers, args.steps, args.warmup)
     stream_bpp = S.projs[0].get_option("packed_millibytes_per_point") / 1000.0  # 12.0 unless the cloud is packed
     n_local = S.hi - S.lo
+    main_stats = sample_stats(S.projs[0], timed_poses, with_filter)  # (the local slice's own frames)
+    if multi:
+        S.sync()
+
+    # Reported separately, N = 1: the layout north_star names -- fp32 SoA xyz (option pack = 0: the point kernel
+    # streams 12 B/pt) -- over the same poses, with its own roofline object
+    fp32_soa = None
+    if not multi and not args.no_extra and stream_bpp < 11.9:
+        proj.set_option("pack", 0)
+        dtf, tf = S.timed_run(renderers, args.steps, args.warmup)
+        kf = kernel_table(tf)
+        stf = sample_stats(proj, timed_poses, with_filter)
+        trf, limf = measured_traffic(args.scene, n_local, W, H, with_filter, pack=0)
+        fp32_soa = {"what": "option pack = 0: the point kernel streams the fp32 SoA coordinates (12 B/pt, the layout "
+                            "BASELINE.json's north_star names) instead of their lossless packed form; same poses, "
+                            "bit-identical frames",
+                    "value": total * args.steps / dtf / 1e6, "unit": "Mpoints/s", "ms_per_step": dtf / args.steps * 1e3,
+                    "steps": args.steps,
+                    "roofline": roofline_of(kf["min_depth"], tf["min_depth"][1], n_local, trf, every, 12.0, stf, limf)
+                                if kf.get("min_depth") else None}
+        proj.set_option("pack", 1)
+
+    # Reported separately, N = 1: the reference's CALL SHAPE -- computeFilteredRGBD copies depth (W*H*4) and colour
+    # (W*H*3) into caller-allocated host arrays every frame (project_cloud.cu:302-309,424-431) -- over the same poses.
+    # Never `value` (inputs and outputs of `value` stay in HBM); this is the PCIe-inclusive rate.
+    host_out = None
+    if not multi and not args.no_extra:
+        img_h, depth_h = np.empty((H, W, 3), np.uint8), np.empty((H, W), np.float32)
+        img_h[...] = 0
+        depth_h[...] = 0  # (pages touched before the timed region)
+        for k in range(args.warmup):
+            proj.project_into(poses[k], img_h, depth_h, with_filter)
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            proj.project_into(poses[args.warmup + k], img_h, depth_h, with_filter)
+        dth = time.perf_counter() - t1
+        host_out = {"what": "rtr_project%s into caller-allocated (pageable) host arrays, synchronous per frame: the "
+                            "reference's call shape, %d bytes over PCIe per frame" %
+                            ("_filtered" if with_filter else "", img_h.nbytes + depth_h.nbytes),
+                    "value": total * args.steps / dth / 1e6, "unit": "Mpoints/s", "ms_per_step": dth / args.steps * 1e3,
+                    "steps": args.steps, "bytes_per_frame": img_h.nbytes + depth_h.nbytes}
+        if hasattr(proj, "project_async"):
+            # the same frames through the asynchronous pair: frame k's copies overlap frame k + 1's kernels
+            outs = [proj.host_output_buffers(j) for j in range(2)]
+            for k in range(args.warmup):
+                proj.project_async(poses[k], k & 1, with_filter)
+            proj.wait_outputs()
+            t1 = time.perf_counter()
+            for k in range(args.steps):
+                proj.project_async(poses[args.warmup + k], k & 1, with_filter)
+            proj.wait_outputs()
+            dta = time.perf_counter() - t1
+            ok = None
+            if not args.no_parity:  # the last frame, against the synchronous call
+                proj.project_into(poses[args.warmup + args.steps - 1], img_h, depth_h, with_filter)
+                io, do = outs[(args.steps - 1) & 1]
+                ok = bool(np.array_equal(io, img_h) and np.array_equal(do.view(np.uint32), depth_h.view(np.uint32)))
+            host_out["async"] = {"what": "rtr_project_async into the library's pinned output buffers (two in rotation), "
+                                         "one rtr_wait at the end: frame k's device-to-host copies run beside frame "
+                                         "k + 1's kernels", "ms_per_step": dta / args.steps * 1e3,
+                                 "value": total * args.steps / dta / 1e6, "unit": "Mpoints/s",
+                                 "equals_sync_call": ok}
+
+    # BASELINE config C2 (N = 1): ~1e7 points -> 1920x1080, z-buffer 1x1 splat only (ScanNet++ is not in the
+    # container: the synthetic room_shell stand-in with C2's seed, SURVEY.md 8d), with its own parity check
+    c2 = None
+    if not multi and not args.no_extra and (args.points, W, H) == (100_000_000, 1920, 1080):
+        n2 = 10_000_000
+        pc = pkg.Projector(local_rank)
+        pc.generate_synthetic("room_shell", SEEDS["C2"], 0, n2, n2)
+        pc.set_resolution(W, H)
+        for k in range(args.warmup):
+            pc.render(poses[k], False)
+        pc.synchronize()
+        pc.timing_enable({0: 0, 1: 2, 2: 4, 4: 3}[every])
+        pc.timing_reset()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            pc.render(poses[args.warmup + k], False)
+        pc.synchronize()
+        dt2 = time.perf_counter() - t1
+        t2 = pc.timing()
+        pc.timing_enable(False)
+        k2 = kernel_table(t2)
+        ok2 = None
+        if not args.no_parity:
+            orc = entry.load_oracle()
+            x2, c2c = pc.download_points()
+            i2, d2 = pc.project(poses[0])
+            r2 = orc.MTProjector(W, H, host_threads()).project(x2, c2c, poses[0])
+            ok2 = bool(np.array_equal(d2.view(np.uint32), r2["depth_bits"]) and np.array_equal(i2, r2["img"]))
+            del x2, c2c, r2
+        bpp2 = pc.get_option("packed_millibytes_per_point") / 1000.0
+        c2 = {"what": "BASELINE C2: %d-point room_shell (seed 0xC0FFEE02) -> %dx%d, projection only (no prefilter)" % (n2, W, H),
+              "value": n2 * args.steps / dt2 / 1e6, "unit": "Mpoints/s", "ms_per_step": dt2 / args.steps * 1e3,
+              "frames_per_s": args.steps / dt2, "steps": args.steps, "parity_vs_oracle": ok2,
+              "roofline": roofline_of(k2["min_depth"], t2["min_depth"][1], n2, None, every, bpp2,
+                                      sample_stats(pc, timed_poses, False)) if k2.get("min_depth") else None}
+        pc.close()
 
     # Reported separately (never part of `value`), N = 1 only.
     extra_cull, ubox, pipelined, rotated = None, None, None, None
@@ -486,7 +620,8 @@ def main():
                        "parity_vs_oracle": bool(np.array_equal(depth_r.view(np.uint32), ref_r["depth_bits"]) and
                                                 np.array_equal(img_r, ref_r["img"])),
                        "roofline": roofline_of(kr["min_depth"], tr["min_depth"][1], total, None, every,
-                                               pr.get_option("packed_millibytes_per_point") / 1000.0)
+                                               pr.get_option("packed_millibytes_per_point") / 1000.0,
+                                               sample_stats(pr, poses_r[args.warmup:args.warmup + m], with_filter))
                                    if kr.get("min_depth") else None}
             pr.close()
             del xr, cr, ref_r
@@ -507,14 +642,16 @@ def main():
                     t_up = time.perf_counter() - t0
                 dtu, tu = U.timed_run(U.renderers("allreduce"), m, args.warmup)
                 ku = kernel_table(tu)
+                stu = sample_stats(U.projs[0], timed_poses, with_filter)
+                tru, limu = measured_traffic("uniform_box" if policy == 0 else "uniform_box_sorted", args.points, W, H,
+                                             with_filter)
                 req, two = frame_bytes(args.points, W, H, with_filter)
                 ubox[key] = {"value": args.points * m / dtu / 1e6, "unit": "Mpoints/s", "ms_per_step": dtu / m * 1e3,
                              "steps": m, "reordered_by_library": bool(U.projs[0].get_option("reordered")),
                              "order_ratio": U.projs[0].get_option("order_ratio_ppm") / 1e6,
-                             "roofline": roofline_of(ku["min_depth"], tu["min_depth"][1], args.points,
-                                                     measured_traffic("uniform_box" if policy == 0 else "uniform_box_sorted",
-                                                                      args.points, W, H, with_filter), every,
-                                                     U.projs[0].get_option("packed_millibytes_per_point") / 1000.0),
+                             "roofline": roofline_of(ku["min_depth"], tu["min_depth"][1], args.points, tru, every,
+                                                     U.projs[0].get_option("packed_millibytes_per_point") / 1000.0, stu,
+                                                     limu),
                              "frame_required_bytes_frac": req / (dtu / m) / 1e9 / HBM_PEAK_GBS}
                 if t_up is not None:
                     ubox[key]["generate_plus_sort_s"] = t_up
@@ -570,7 +707,11 @@ def main():
                                                     depth_k))) if multi else
                        ("single GPU" + (", %d frames in flight" % depth_k if depth_k > 1 else ""))},
             "roofline": roofline_of(kern[dom], timing[dom][1], n_local,
-                                    measured_traffic(args.scene, n_local, W, H, with_filter), every, stream_bpp)
+                                    *measured_traffic(args.scene, n_local, W, H, with_filter,
+                                                      pack=1 if stream_bpp < 11.9 else 0)[:1], every, stream_bpp,
+                                    main_stats if dom == "min_depth" else None,
+                                    measured_traffic(args.scene, n_local, W, H, with_filter,
+                                                     pack=1 if stream_bpp < 11.9 else 0)[1])
                         if kern.get(dom) else None,
             # the frame against the bytes THIS design has to move (cloud streamed once: 12 B/pt, 39 B/px of
             # clear / resolve work, ~50 B/px of prefilter) ...
@@ -585,6 +726,9 @@ def main():
             "kernel_ms": kern,
             "parity_vs_oracle": parity,
             "parity_vs_single_gpu": parity_single,
+            "fp32_soa": fp32_soa,
+            "c2": c2,
+            "host_outputs": host_out,
             "rotated_noisy_scene": rotated,
             "uniform_box": ubox,
             "pipelined": pipelined,

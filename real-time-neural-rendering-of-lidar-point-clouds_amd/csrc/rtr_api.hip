@@ -94,6 +94,7 @@ struct rtr_ctx {
         uint32_t *occ = nullptr;          // [128] one bit per screen tile: this rank's frame has entries there
         uint32_t *occ_all = nullptr;      // [kMaxPeers * 128] every rank's bitmap, gathered by the first barrier of a frame
         bool depth_peers = false;         // rtr_p2p_render: the accumulate launch takes the MIN over the peers' depth itself
+        bool depth_in_red = false;        // ... and has left the completed depth in `red` (the peers were reading `depth`)
         bool occ_current = false;         // occ was computed from the bins that are valid now
         bool occ_from_scan = false;       // ... by the epilogue of this frame's T1 (no separate launch)
         bool whole_frame = false;         // inside rtr_p2p_render: the tile launches are the only writers of depth /
@@ -1051,6 +1052,8 @@ int rtr_accumulate_pass(rtr_ctx *c, const float P[16]) {
             dsl.src = c->p2p.depth;
             dsl.peers = c->p2p.world;
             dsl.occ_all = c->p2p.occ_all;
+            dsl.out = c->p2p.red;  // (nobody reads `red` in this form; RTR_BUF_DEPTH is completed from it below)
+            c->p2p.depth_in_red = true;
         } else if (c->p2p.whole_frame && c->p2p.depth_sliced) {
             dsl.src = c->p2p.reduced;
             dsl.chunk = p2p_slice(c).chunk;
@@ -1087,14 +1090,16 @@ int rtr_resolve_range(rtr_ctx *c, const void *acc_dev, uint64_t first_pixel, uin
     return launch_check(c, "resolve_range");
 }
 
-static int filter_impl(rtr_ctx *c, int pyramid_parts, const rtr::Sliced *img_slices = nullptr) {
+static int filter_impl(rtr_ctx *c, int pyramid_parts, const rtr::Sliced *img_slices = nullptr,
+                       const uint32_t *depth_src = nullptr) {
     if (int rc = check_frame(c)) return rc;
     DevGuard g(c->device);
     if (int rc = ensure_pyramid(c)) return rc;
     {
         Timed t(c, RTR_K_FILTER);
         rtr::launch_filter(c->stream, c->lv, c->depth, c->img, c->mask, c->tensor, c->minmax, c->part_min, c->part_max,
-                           c->W, c->H, c->prm.filter_strength, c->prm.gradient_threshold, pyramid_parts, img_slices);
+                           c->W, c->H, c->prm.filter_strength, c->prm.gradient_threshold, pyramid_parts, img_slices,
+                           depth_src);
     }
     return launch_check(c, "filter");
 }
@@ -1369,8 +1374,17 @@ int rtr_p2p_render(rtr_ctx *c, const float P[16], int with_filter) {
         isl.src = q.image;
         isl.chunk = p2p_slice(c).chunk;
     }
-    q.whole_frame = q.pyramid_done = q.depth_sliced = q.depth_peers = q.image_sliced = false;
-    if (!rc && with_filter) rc = filter_impl(c, parts, isl.chunk ? &isl : nullptr);
+    // One-barrier form: the completed depth lies in `red`.  Every rank is past its accumulate launch (the barriers
+    // of the colour exchange), so nobody reads this rank's depth buffer any more: the fused prefilter reads `red`
+    // and writes RTR_BUF_DEPTH; without a prefilter (or with another pyramid depth) a device copy completes it.
+    const bool from_red = q.depth_in_red;
+    const bool fused = with_filter && c->prm.levels == 4;
+    q.whole_frame = q.pyramid_done = q.depth_sliced = q.depth_peers = q.image_sliced = q.depth_in_red = false;
+    if (!rc && from_red && !fused) {
+        DevGuard g(c->device);
+        HIP_TRY(c, hipMemcpyAsync(c->depth, q.red, (size_t)c->W * c->H * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (!rc && with_filter) rc = filter_impl(c, parts, isl.chunk ? &isl : nullptr, (from_red && fused) ? q.red : nullptr);
     return rc;
 }
 

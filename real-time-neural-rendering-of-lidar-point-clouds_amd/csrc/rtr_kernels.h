@@ -54,12 +54,14 @@ struct PeerSet {
 // chunk == 0: not sliced, use the local buffer.
 // peers > 0 (accumulate pass of a sharded whole frame): src.p[r] is rank r's LOCAL depth buffer and the
 // element is the MIN over the ranks whose bit for the tile is set in occ_all[r * 128 + (tile >> 5)] (every
-// rank's occupancy bitmap, gathered into local memory by the barrier launch).
+// rank's occupancy bitmap, gathered into local memory by the barrier launch); the completed depth goes to `out`,
+// a buffer no peer reads in that launch (NOT into the local depth buffer the peers are reading at that moment).
 struct Sliced {
     PeerSet src;
     size_t chunk;
     const uint32_t *occ_all;
     int peers;
+    uint32_t *out;
 };
 struct TilePyr {  // F1 folded into T4 (whole-frame calls with the default 4 levels)
     FilterLevels L;
@@ -192,10 +194,12 @@ void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, floa
                  uint32_t *acc, uint8_t *img, int write_acc, const TilePyr *pyr, const Sliced *depth_slices = nullptr);
 void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *sink, int variant);
 void launch_resolve(hipStream_t s, const uint32_t *acc, uint8_t *img, size_t npix);
-// img_slices (4 levels only): read the input image from the ranks' resolved slices (chunk in pixels)
+// img_slices (4 levels only): read the input image from the ranks' resolved slices (chunk in pixels);
+// depth_src (4 levels only): read the unfiltered depth from this buffer instead of depth_bits (which is written)
 void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, uint8_t *img, uint8_t *mask,
                    uint16_t *tensor, uint32_t *minmax, uint32_t *part_min, uint32_t *part_max, int W, int H,
-                   float strength, float thr, int pyramid_parts, const Sliced *img_slices = nullptr);
+                   float strength, float thr, int pyramid_parts, const Sliced *img_slices = nullptr,
+                   const uint32_t *depth_src = nullptr);
 void launch_p2p_sync(hipStream_t s, uint32_t *my_flags, const PeerSet &peer_flags, int rank, int world, uint32_t seq,
                      uint32_t *status, unsigned long long timeout_ticks);
 // the same barrier + every rank's occupancy bitmap gathered into occ_all[world * 128] (local memory)

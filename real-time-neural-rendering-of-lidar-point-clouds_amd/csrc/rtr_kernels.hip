@@ -1480,9 +1480,9 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
                                 v = u < v ? u : v;
                             }
                         s_depth[p] = v;
-                        // (a peer may be reading this word right now: it sees this rank's minimum or the global one,
-                        // and takes the MIN over all ranks either way)
-                        if (sub == 0) depth[gp] = v;  // ... and this launch is what completes RTR_BUF_DEPTH
+                        // (the peers are reading this rank's `depth` right now: the completed frame goes to a buffer
+                        // of its own and reaches RTR_BUF_DEPTH once every rank is past this launch)
+                        if (sub == 0) dsl.out[gp] = v;
                     } else if (dsl.chunk) {  // sharded frame: the global minimum lies in the ranks' reduced slices
                         const uint32_t v = static_cast<const uint32_t *>(dsl.src.p[gp / dsl.chunk])[gp];
                         s_depth[p] = v;
@@ -2008,6 +2008,7 @@ void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, floa
     Sliced nosl{};
     nosl.chunk = 0;
     nosl.peers = 0;
+    nosl.out = nullptr;
     size_t tpix = (size_t)32 << g.tw_shift;
     size_t lds = (mode == 1 ? tpix : 5 * tpix) * sizeof(uint32_t) + ((mode == 0 || mode == 3) ? 3 * tpix : 0);
     TilePyr none{};
@@ -2467,7 +2468,8 @@ __global__ __launch_bounds__(kBlock) void k_filter4(const float *__restrict__ g1
                                                     const uint32_t *__restrict__ part_min,
                                                     const uint32_t *__restrict__ part_max, int nparts,
                                                     uint32_t *__restrict__ minmax, int W, int H, int blocks_x,
-                                                    float strength, float thr, Sliced isl) {
+                                                    float strength, float thr, Sliced isl,
+                                                    const float *__restrict__ depth_src) {
     __shared__ float s1[kF1x * kF1y], s2[kF2x * kF2y], s3[kF3x * kF3y], s4[kF4x * kF4y];
     __shared__ uint32_t s_mm[8];
     __shared__ uint16_t s_lut[256];  // colour byte -> fp16 bits: one IEEE division per thread instead of twelve
@@ -2481,7 +2483,7 @@ __global__ __launch_bounds__(kBlock) void k_filter4(const float *__restrict__ g1
     float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t iw0 = 0, iw1 = 0, iw2 = 0;
     if (inb) {
-        d4 = *reinterpret_cast<const float4 *>(depth + idx);
+        d4 = *reinterpret_cast<const float4 *>(depth_src + idx);
         // sharded frame: the resolved image still lies in the ranks' slices (16-pixel multiples: a quad has one owner)
         const uint8_t *src = isl.chunk ? static_cast<const uint8_t *>(isl.src.p[idx / isl.chunk]) : img;
         const uint32_t *ip = reinterpret_cast<const uint32_t *>(src + idx * 3);
@@ -2537,7 +2539,7 @@ __global__ __launch_bounds__(kBlock) void k_filter4(const float *__restrict__ g1
 // A14 applyDepthFilter (project_cloud.cu:331-392)
 void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, uint8_t *img, uint8_t *mask,
                    uint16_t *tensor, uint32_t *minmax, uint32_t *part_min, uint32_t *part_max, int W, int H,
-                   float strength, float thr, int pyramid_parts, const Sliced *img_slices) {
+                   float strength, float thr, int pyramid_parts, const Sliced *img_slices, const uint32_t *depth_src) {
     auto blocks = [](size_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); };
     const int nl = L.levels;
     const int h_eff = (H >> nl) << nl;
@@ -2550,7 +2552,7 @@ void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, u
         hipLaunchKernelGGL(k_filter4, dim3(bx * by), dim3(kBlock), 0, s, L.lv[1], L.lv[2], L.lv[3], L.lv[4], L.h[4],
                            (float *)depth_bits, img, mask, tensor, part_min, part_max,
                            pyramid_parts > 0 ? pyramid_parts : nparts, minmax, W, H, bx, strength, thr,
-                           img_slices ? *img_slices : Sliced{});
+                           img_slices ? *img_slices : Sliced{}, (const float *)(depth_src ? depth_src : depth_bits));
         return;
     }
     {
@@ -2584,9 +2586,11 @@ void launch_filter(hipStream_t s, const FilterLevels &L, uint32_t *depth_bits, u
 // the peers' frame buffers mapped through hipIpc, xGMI reads).  The pixel range is cut into
 // `world` slices of `chunk` pixels; a rank reduces ITS slice over all ranks' buffers (pull), then
 // every rank collects the reduced slices.  Data only ever crosses a process boundary between
-// kernels -- a buffer is written by one launch and read remotely by a later one, ordered by the
-// flag barrier below -- so ordinary (coarse-grained) device memory is enough; only the flags
-// live in uncached memory and are accessed with system-scope atomics.
+// kernels -- a buffer is written by one launch and read remotely by a LATER one, ordered by the
+// flag barrier below, and never written while a peer may read it (the one-barrier depth exchange of
+// rtr_p2p_render writes the completed depth to a buffer of its own for that reason) -- so ordinary
+// (coarse-grained) device memory is enough; only the flags live in uncached memory and are accessed
+// with system-scope atomics.
 //
 // Barrier: every rank owns flags[world]; a rank entering barrier number `seq` stores seq into
 // flags[rank] of every peer and then waits until its own flags[r] >= seq for all r.  All ranks run

@@ -144,6 +144,12 @@ class Projector:
         self._chk(fn(self._ctx, _vp(P), _vp(img), _vp(depth)))
         return img, depth
 
+    def project_into(self, P, img, depth, filtered=False):
+        """The reference's call shape: fills caller-allocated arrays (either may be None), synchronous."""
+        P = self._P(P)
+        fn = self._lib.rtr_project_filtered if filtered else self._lib.rtr_project
+        self._chk(fn(self._ctx, _vp(P), _vp(img), _vp(depth)))
+
     def render(self, P, with_filter=False):
         P = self._P(P)
         self._chk(self._lib.rtr_render(self._ctx, _vp(P), 1 if with_filter else 0))

@@ -489,6 +489,41 @@ def test_hot_tile_is_split_in_the_binned_form(pkg, orc, projector):
         assert np.array_equal(img, ri), k
 
 
+def test_tile_store_error_reaches_the_caller(pkg, orc, projector):
+    """A tile store that has to drop entries must never hand back a wrong frame as RTR_OK.  Option "debug_dyn_cap"
+    shrinks the pool of dynamic stream extents so that a tile with more than 4096 entries overflows it (error
+    code 2): the synchronous calls, rtr_synchronize and the frame statistics report it, the word is per frame
+    (the next good frame reads 0 again and is exact)."""
+    rng = np.random.default_rng(5)
+    n = 60_000
+    xyz = np.stack([rng.uniform(-0.05, 0.05, n), rng.uniform(-0.05, 0.05, n), rng.uniform(1.9, 2.1, n)], axis=1)
+    rgb = rng.integers(0, 256, size=(n, 3), dtype=np.uint8)
+    xyzw, rgba = cloud(xyz.astype(np.float32), rgb)
+    P = kat_P(orc)  # everything lands in a 10x10 pixel patch of one tile: ~n entries in one or two streams
+    projector.upload_points(xyzw, rgba)
+    projector.set_resolution(64, 48)
+    projector.set_option("split_threshold", 0)
+    try:
+        projector.set_option("debug_dyn_cap", 16)
+        with pytest.raises(pkg._lib.RtrError) as e1:
+            projector.project(P)
+        assert e1.value.code == pkg._lib.RTR_ERR_INTERNAL and "pool" in str(e1.value)
+        assert projector.frame_stats()["errors"] & 2
+        projector.render(P)  # the asynchronous form: the error surfaces at the next synchronising call
+        with pytest.raises(pkg._lib.RtrError) as e2:
+            projector.synchronize()
+        assert e2.value.code == pkg._lib.RTR_ERR_INTERNAL
+        projector.synchronize()  # reported once
+    finally:
+        projector.set_option("debug_dyn_cap", -1)
+        projector.set_option("split_threshold", 32768)
+    img, depth = projector.project(P)
+    st = projector.frame_stats()
+    assert st["errors"] == 0 and st["entries"] == n and st["colour_chunks"] >= n // 256, st
+    ref = orc.project(xyzw, rgba, P, 64, 48)
+    assert np.array_equal(depth.view(np.uint32), ref["depth_bits"]) and np.array_equal(img, ref["img"])
+
+
 def test_ten_million_points_in_one_tile(pkg, orc, projector):
     """1e7 points inside one 32x32 tile (a distant overview): the tile kernel splits the tile over
     hundreds of workgroups; depth, image, accumulators and the filtered outputs against the oracle."""
