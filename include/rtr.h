@@ -177,6 +177,21 @@ int rtr_project_filtered(rtr_ctx *ctx, const float P[16], uint8_t *host_img, flo
 /* Same frame sequences without any host copy or host sync (outputs stay in HBM). */
 int rtr_render(rtr_ctx *ctx, const float P[16], int with_filter);
 
+/* ---- 4b. the same frames with the host copies off the critical path ---------------
+ * The reference's call shape runs the kernels and then the two device-to-host copies (W*H*4 + W*H*3 bytes:
+ * 14.5 MB at 1080p, ~0.29 ms over PCIe) one after the other, every frame (project_cloud.cu:302-309,424-431).
+ * rtr_project_async renders a frame like rtr_project / rtr_project_filtered, snapshots depth and image on the
+ * device and queues their copies into the library's PINNED host buffers of `slot` on a second stream; it does
+ * not wait.  With the slots used in rotation, frame k's copies run beside frame k + 1's kernels.
+ * rtr_wait(slot) blocks until that slot's outputs are complete (slot = -1: all of them) and reports errors of
+ * the frames since the last synchronising call; the buffers (rtr_host_output_buffers: W*H*3 u8, W*H float,
+ * valid until the next rtr_set_resolution) may be read until the slot is used again.  A caller that needs the
+ * frame in its own arrays copies from there (or keeps using the synchronous calls). */
+#define RTR_ASYNC_SLOTS 2
+int rtr_host_output_buffers(rtr_ctx *ctx, int slot, uint8_t **img, float **depth);
+int rtr_project_async(rtr_ctx *ctx, const float P[16], int slot, int with_filter);
+int rtr_wait(rtr_ctx *ctx, int slot);
+
 /* ---- 5. phase calls (multi-GPU sharding: reduce between phases) ----------------- */
 /*   rtr_clear -> rtr_min_depth_pass -> [all-reduce MIN of depth]
  *   -> rtr_accumulate_pass -> [all-reduce / reduce-scatter SUM of accum]

@@ -22,7 +22,7 @@ SYMBOLS = [
     "rtr_filter", "rtr_device_buffer", "rtr_download_buffer", "rtr_timing_enable", "rtr_timing_reset",
     "rtr_timing_get", "rtr_set_option", "rtr_stream_probe", "rtr_resolve_range", "rtr_reorder_points", "rtr_reset_stream",
     "rtr_device_count", "rtr_p2p_export", "rtr_p2p_open", "rtr_p2p_close", "rtr_p2p_min_depth", "rtr_p2p_sum_resolve", "rtr_p2p_status",
-    "rtr_p2p_render", "rtr_frame_stats", "rtr_get_option",
+    "rtr_p2p_render", "rtr_frame_stats", "rtr_get_option", "rtr_host_output_buffers", "rtr_project_async", "rtr_wait",
 ]
 
 RTR_OK, RTR_ERR_INVALID, RTR_ERR_HIP, RTR_ERR_NO_OUTPUT, RTR_ERR_UNSUPPORTED, RTR_ERR_INTERNAL = 0, -1, -2, -3, -4, -5
@@ -109,6 +109,9 @@ def lib():
     L.rtr_p2p_render.argtypes = [vp, vp, i32]
     L.rtr_frame_stats.argtypes = [vp, vp]
     L.rtr_get_option.argtypes = [vp, C.c_char_p, C.POINTER(i32)]
+    L.rtr_host_output_buffers.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
+    L.rtr_project_async.argtypes = [vp, vp, i32, i32]
+    L.rtr_wait.argtypes = [vp, i32]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("rtr_last_error", "rtr_default_params"):

@@ -112,6 +112,18 @@ struct rtr_ctx {
         bool open = false;
     } p2p;
 
+    // asynchronous host outputs (rtr_project_async): per slot a device snapshot of depth + image (so the next
+    // frame's kernels may overwrite the frame buffers), pinned host buffers, and the events that order the two
+    // streams -- the device-to-host copies run on `copy_stream` beside the next frame's kernels
+    struct HostOut {
+        uint8_t *img = nullptr, *dimg = nullptr;
+        float *depth = nullptr;
+        uint32_t *ddepth = nullptr;
+        hipEvent_t snap = nullptr, done = nullptr;  // snapshot taken (frame stream) / copies finished (copy stream)
+        bool busy = false;
+    } ho[RTR_ASYNC_SLOTS];
+    hipStream_t copy_stream = nullptr;
+
     // timing
     int timing = 0;  // 0 off, 1 every phase, 2 only the streaming kernel (RTR_K_MIN_DEPTH / ACCUMULATE), 3 = 2 on every 4th launch
     uint32_t timing_tick = 0;
@@ -191,8 +203,21 @@ Slice p2p_slice(const rtr_ctx *c) {  // pixels owned by this rank: slices are mu
     s.count = (npix - s.first) < s.chunk ? npix - s.first : s.chunk;
     return s;
 }
+void free_host_out(rtr_ctx *c) {
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    for (auto &h : c->ho) {
+        if (h.img) (void)hipHostFree(h.img);
+        if (h.depth) (void)hipHostFree(h.depth);
+        dfree(h.dimg); dfree(h.ddepth);
+        if (h.snap) (void)hipEventDestroy(h.snap);
+        if (h.done) (void)hipEventDestroy(h.done);
+        h = rtr_ctx::HostOut{};
+    }
+}
+
 void free_frame(rtr_ctx *c) {
     c->list_valid = false;
+    free_host_out(c);
     p2p_release(c);
     dfree(c->depth); dfree(c->acc); dfree(c->img); dfree(c->mask); dfree(c->part_min); dfree(c->part_max); dfree(c->tensor);
     for (int i = 1; i <= 8; ++i) dfree(c->lv.lv[i]);
@@ -489,6 +514,7 @@ int rtr_destroy(rtr_ctx *c) {
     dfree(c->minmax);
     if (c->p2p.status_host) (void)hipHostFree(c->p2p.status_host);
     if (c->err_host) (void)hipHostFree(c->err_host);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return RTR_OK;
@@ -760,11 +786,11 @@ static int pack_cloud(rtr_ctx *c) {
     uint64_t host[2] = {0, 0};
     if (hipMemcpyAsync(host, tot.p, sizeof host, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return give_up();
     if (hipStreamSynchronize(c->stream) != hipSuccess) return give_up();
-    const uint64_t bytes = host[0] * 256 + nchunks * 32;
+    const uint64_t bytes = host[0] * 32 + nchunks * 32;  // blocks (32-byte units) + headers
     if (c->opt_pack == 1 && bytes * 8 > n4 * 48 * 7) return give_up();  // saves less than 1/8 of the 12 B/pt stream
-    // (one spare plane: the last lane's 16-byte load runs up to 12 bytes past the chunk's last value)
-    if (hipMalloc((void **)&planes, (host[0] + 1) * 256) != hipSuccess) return give_up();
-    if (hipMemsetAsync(planes + host[0] * 64, 0, 256, c->stream) != hipSuccess) return give_up();
+    // (spare bytes: the last lanes' 16-byte loads run up to 12 bytes past the chunk's last value)
+    if (hipMalloc((void **)&planes, (host[0] + 2) * 32) != hipSuccess) return give_up();
+    if (hipMemsetAsync(planes + host[0] * 8, 0, 64, c->stream) != hipSuccess) return give_up();
     rtr::pack_write(c->stream, cl, hdr, planes);
     if (c->opt_pack == 2) {
         rtr::pack_verify(c->stream, cl, hdr, planes, (uint64_t *)tot.p + 1);
@@ -1179,6 +1205,73 @@ static int frame_to_host(rtr_ctx *c, const float P[16], uint8_t *host_img, float
 
 int rtr_project(rtr_ctx *c, const float P[16], uint8_t *host_img, float *host_depth) {
     return frame_to_host(c, P, host_img, host_depth, 0);
+}
+
+// ---- asynchronous host outputs ------------------------------------------------------------
+// The reference's call shape pays kernels + 14.5 MB over PCIe per 1080p frame, one after the other
+// (project_cloud.cu:302-309,424-431).  Here frame k's copies run on a second stream (the SDMA engines) beside
+// frame k + 1's kernels: depth and image are snapshotted on the device first (two device copies, ~10 us), so the
+// frame buffers are free again at once.
+
+static int ensure_host_out(rtr_ctx *c) {
+    if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    const size_t npix = (size_t)c->W * c->H;
+    for (auto &h : c->ho) {
+        if (h.img) continue;
+        HIP_TRY(c, hipHostMalloc((void **)&h.img, npix * 3, hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc((void **)&h.depth, npix * 4, hipHostMallocDefault));
+        HIP_TRY(c, hipMalloc((void **)&h.dimg, (npix * 3 + 15) & ~(size_t)15));
+        HIP_TRY(c, hipMalloc((void **)&h.ddepth, npix * 4));
+        HIP_TRY(c, hipEventCreateWithFlags(&h.snap, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&h.done, hipEventDisableTiming));
+    }
+    return RTR_OK;
+}
+
+int rtr_host_output_buffers(rtr_ctx *c, int slot, uint8_t **img, float **depth) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, slot >= 0 && slot < RTR_ASYNC_SLOTS, "slot out of range");
+    if (int rc = check_frame(c)) return rc;
+    DevGuard g(c->device);
+    if (int rc = ensure_host_out(c)) return rc;
+    if (img) *img = c->ho[slot].img;
+    if (depth) *depth = c->ho[slot].depth;
+    return RTR_OK;
+}
+
+int rtr_project_async(rtr_ctx *c, const float P[16], int slot, int with_filter) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, P != nullptr, "P is NULL");
+    NEED(c, slot >= 0 && slot < RTR_ASYNC_SLOTS, "slot out of range");
+    if (int rc = check_frame(c)) return rc;
+    DevGuard g(c->device);
+    if (int rc = ensure_host_out(c)) return rc;
+    auto &h = c->ho[slot];
+    // (the slot's previous frame may still be on its way to the host: its snapshot must not be overwritten yet)
+    if (h.busy) HIP_TRY(c, hipStreamWaitEvent(c->stream, h.done, 0));
+    if (int rc = rtr_render(c, P, with_filter)) return rc;
+    const size_t npix = (size_t)c->W * c->H;
+    HIP_TRY(c, hipMemcpyAsync(h.ddepth, c->depth, npix * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h.dimg, c->img, npix * 3, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(h.snap, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, h.snap, 0));
+    HIP_TRY(c, hipMemcpyAsync(h.depth, h.ddepth, npix * 4, hipMemcpyDeviceToHost, c->copy_stream));
+    HIP_TRY(c, hipMemcpyAsync(h.img, h.dimg, npix * 3, hipMemcpyDeviceToHost, c->copy_stream));
+    HIP_TRY(c, hipEventRecord(h.done, c->copy_stream));
+    h.busy = true;
+    return RTR_OK;
+}
+
+int rtr_wait(rtr_ctx *c, int slot) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, slot >= -1 && slot < RTR_ASYNC_SLOTS, "slot out of range (-1: every slot)");
+    DevGuard g(c->device);
+    for (int k = 0; k < RTR_ASYNC_SLOTS; ++k) {
+        if ((slot >= 0 && k != slot) || !c->ho[k].busy) continue;
+        HIP_TRY(c, hipEventSynchronize(c->ho[k].done));
+        c->ho[k].busy = false;
+    }
+    return check_store_error(c);
 }
 
 int rtr_project_filtered(rtr_ctx *c, const float P[16], uint8_t *host_img, float *host_depth) {

@@ -15,15 +15,19 @@ struct Proj {
 
 // Lossless resident form of the coordinates for the tile-binned point kernel (option "pack").  A chunk =
 // 256 consecutive points = what one wave handles per iteration (lane l: points 4 l .. 4 l + 3).  Per
-// chunk and axis the fp32 BIT PATTERNS are stored as base | low bytes: base = the leading bits all 256
-// patterns share (low 8 w bits clear), w = 0..4 the number of bytes below that common prefix (0: the axis
-// is constant in the chunk; 4: nothing is shared -- NaNs, mixed signs).  An axis block is the 256 values'
-// low w bytes back to back (lane l's four values at byte 4 w l): 256 w bytes, read with ONE unaligned
-// 16-byte load per lane; a chunk is its x, y, z blocks = wx + wy + wz "planes" of 256 bytes.
-// hdr[2 c] = {base x, base y, base z, wx | wy << 3 | wz << 6}, hdr[2 c + 1] = {first plane (lo, hi), 0, 0}.
-// The plane buffer ends with one spare plane (the last lane's 16-byte load runs past its values).
-// Spatially ordered clouds need 2-3 bytes per coordinate (neighbours share sign, exponent and leading
-// mantissa bits): 6-9 B/pt instead of 12, decoded with one byte-permute per value.
+// chunk and axis the fp32 BIT PATTERNS are stored as base | low bits: base = the leading bits all 256
+// patterns share (low b bits clear), b = 0..25 or 32 the number of bits below that common prefix (0: the axis
+// is constant in the chunk; 32: nothing is shared -- NaNs, mixed signs -- or more than 25 bits differ).  An
+// axis block is the 256 values' low b bits back to back as one little-endian bit stream (lane l's four values
+// at bit 4 b l): 32 b bytes, read with ONE dword-aligned 16-byte load per lane (the lane shifts its data down by
+// the 0..28 bits its first value starts into that dword); a chunk is its x, y, z blocks.
+// hdr[2 c] = {base x, base y, base z, bx | by << 6 | bz << 12 | kPackWideFlag if some b is 32},
+// hdr[2 c + 1] = {first 32-byte unit (lo, hi), 0, 0}.
+// The buffer ends with spare bytes (the last lanes' 16-byte loads run past their values).
+// Spatially ordered clouds need 16-21 bits per coordinate (neighbours share sign, exponent and leading
+// mantissa bits): 5-8 B/pt instead of 12 (round 2 stored whole bytes: 6.5-9.2 B/pt).
+constexpr uint32_t kPackMaxBits = 25;  // shift (<= 28) + 4 b <= 128 bits of a lane's load
+constexpr uint32_t kPackWideFlag = 1u << 18;
 struct PackedXyz {
     const uint4 *hdr;        // null: not packed
     const uint32_t *planes;
@@ -171,8 +175,8 @@ void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int
                         const float *bounds, int clear_split, int phases, int xp = 0, hipEvent_t ev_start = nullptr,
                         hipEvent_t ev_stop = nullptr);  // ev_*: time stamps taken by the dispatch itself (timing on)
 void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds);  // 6 floats per 256 points
-// packing (see PackedXyz): pack_measure fills hdr[2 nchunks] (bases, widths, plane offsets by an exclusive
-// scan) and *total_planes (device); pack_write fills the planes; pack_verify counts the points whose decoded
+// packing (see PackedXyz): pack_measure fills hdr[2 nchunks] (bases, widths, block offsets by an exclusive
+// scan) and *total_planes (device; in 32-byte units); pack_write fills the blocks; pack_verify counts the points whose decoded
 // coordinates differ from the raw ones (must be 0) into *mismatches (device).  nchunks = ceil(ceil(n / 4) / 64).
 void pack_measure(hipStream_t s, const Cloud &c, uint4 *hdr, uint32_t *chunk_planes, uint64_t *total_planes);
 void pack_write(hipStream_t s, const Cloud &c, const uint4 *hdr, uint32_t *planes);

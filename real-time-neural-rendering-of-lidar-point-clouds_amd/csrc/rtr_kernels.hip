@@ -711,71 +711,73 @@ __device__ void next_frame_order(const TileStore &S) {
 }
 
 // PackedXyz helpers ---------------------------------------------------------------
-// One UNALIGNED 16-byte load per axis and lane, whatever the width: lane l's four w-byte values start at
-// byte 4 w l of the axis block, so the load covers them (and up to 12 bytes of its neighbour's -- the buffer
-// ends with spare bytes).  A fixed number of loads per chunk, no branch around any of them.
+// An axis block is one little-endian bit stream: lane l's four b-bit values are bits [4 b l, 4 b l + 4 b), value k
+// at + b k.  A lane reads the 16 bytes that start at the DWORD holding its first bit (loads whose lane stride is not
+// a multiple of four bytes run at a third of the rate: 2.2-3.8 TB/s against 7.0, tools/align_probe.hip) and shifts
+// its data down by the remaining 0..28 bits; b <= 25 keeps shift + 4 b <= 128.  A fixed number of loads per chunk
+// (one per axis), no branch around any of them; the buffer ends with spare bytes for the last lane's over-read.
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 struct AxisRaw { uint32_t d[4]; };
-__device__ __forceinline__ AxisRaw ld_axis(const uint8_t *block, uint32_t w, int lane) {
-    const u32x4_a4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4 *>(block + 4u * w * (uint32_t)lane));
+__device__ __forceinline__ AxisRaw ld_axis(const uint8_t *block, uint32_t b, int lane) {
+    const uint32_t dw = (b * (uint32_t)lane) >> 3;  // (4 b l) >> 5
+    const u32x4_a4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4 *>(block + 4u * dw));
     return AxisRaw{{v.x, v.y, v.z, v.w}};
 }
-// v_perm_b32(S0, S1, sel): selector byte 0-3 picks a byte of S1 (the second argument), 4-7 a byte of S0.
-// base has its low 8 w bits clear; value k = base | bytes [k w, k w + w) of the lane's 16 bytes: one permute
-// per value (two for the 3-byte values that straddle a dword).  w is wave-uniform.
-__device__ __forceinline__ float4 unpack_axis(const AxisRaw &r, uint32_t w, uint32_t base) {
-    uint32_t x[4];
-    if (w == 0u) {
-        x[0] = x[1] = x[2] = x[3] = base;
-    } else if (w == 3u) {
-        x[0] = __builtin_amdgcn_perm(base, r.d[0], 0x07020100u);
-        x[1] = __builtin_amdgcn_perm(base, __builtin_amdgcn_alignbit(r.d[1], r.d[0], 24), 0x07020100u);
-        x[2] = __builtin_amdgcn_perm(base, __builtin_amdgcn_alignbit(r.d[2], r.d[1], 16), 0x07020100u);
-        x[3] = __builtin_amdgcn_perm(base, r.d[2], 0x07030201u);
-    } else if (w == 2u) {
-        x[0] = __builtin_amdgcn_perm(base, r.d[0], 0x07060100u);
-        x[1] = __builtin_amdgcn_perm(base, r.d[0], 0x07060302u);
-        x[2] = __builtin_amdgcn_perm(base, r.d[1], 0x07060100u);
-        x[3] = __builtin_amdgcn_perm(base, r.d[1], 0x07060302u);
-    } else if (w == 1u) {
-        x[0] = __builtin_amdgcn_perm(base, r.d[0], 0x07060500u);
-        x[1] = __builtin_amdgcn_perm(base, r.d[0], 0x07060501u);
-        x[2] = __builtin_amdgcn_perm(base, r.d[0], 0x07060502u);
-        x[3] = __builtin_amdgcn_perm(base, r.d[0], 0x07060503u);
-    } else {
-        x[0] = r.d[0], x[1] = r.d[1], x[2] = r.d[2], x[3] = r.d[3];
-    }
-    return make_float4(__uint_as_float(x[0]), __uint_as_float(x[1]), __uint_as_float(x[2]), __uint_as_float(x[3]));
+// value k = base | bits [b k, b k + b) of the lane's realigned data.  Branch-free for every b <= 25 (b = 0: the mask is
+// empty and the value is the base): the lane's 128 bits are shifted down by its sub-dword offset (four v_alignbit
+// with a per-lane shift), then three more times by b, each time one dword less of it (3 + 2 + 1 v_alignbit with a
+// scalar shift); every value is the low dword of one of those, masked and OR-ed onto the base.  A first version
+// picked the dwords a value straddles by width class behind wave-uniform branches: ~10 branches per axis made the
+// point kernel 14 us slower than the byte-granular form it was meant to beat.  b is wave-uniform.
+__device__ __forceinline__ float4 unpack_axis_narrow(const AxisRaw &r, uint32_t b, uint32_t base, int lane) {
+    // (a VOP3 instruction reads at most one scalar register on gfx950: with mask AND base scalar the compiler splits every
+    // v_and_or into two instructions; the base in a vector register keeps it one)
+    uint32_t vbase = base;
+    asm("" : "+v"(vbase));
+    const uint32_t sh = ((b * (uint32_t)lane) & 7u) << 2;  // (4 b l) & 31
+    const uint32_t mask = (1u << b) - 1u;                    // (b <= 25)
+    const uint32_t e0 = __builtin_amdgcn_alignbit(r.d[1], r.d[0], sh), e1 = __builtin_amdgcn_alignbit(r.d[2], r.d[1], sh);
+    const uint32_t e2 = __builtin_amdgcn_alignbit(r.d[3], r.d[2], sh), e3 = r.d[3] >> sh;
+    const uint32_t f0 = __builtin_amdgcn_alignbit(e1, e0, b), f1 = __builtin_amdgcn_alignbit(e2, e1, b);
+    const uint32_t f2 = __builtin_amdgcn_alignbit(e3, e2, b);
+    const uint32_t g0 = __builtin_amdgcn_alignbit(f1, f0, b), g1 = __builtin_amdgcn_alignbit(f2, f1, b);
+    const uint32_t h0 = __builtin_amdgcn_alignbit(g1, g0, b);
+    auto and_or = [&](uint32_t e) -> float {  // (the compiler leaves v_and + v_or here)
+        uint32_t x;
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(x) : "v"(e), "s"(mask), "v"(vbase));
+        return __uint_as_float(x);
+    };
+    return make_float4(and_or(e0), and_or(f0), and_or(g0), and_or(h0));
+}
+__device__ __forceinline__ float4 unpack_axis(const AxisRaw &r, uint32_t b, uint32_t base, int lane) {
+    if (b == 32u)  // (lane l's four values are its four dwords)
+        return make_float4(__uint_as_float(r.d[0]), __uint_as_float(r.d[1]), __uint_as_float(r.d[2]), __uint_as_float(r.d[3]));
+    return unpack_axis_narrow(r, b, base, lane);
 }
 struct ChunkRaw { AxisRaw a[3]; };
 __device__ __forceinline__ ChunkRaw load_chunk(const uint32_t *__restrict__ planes, const uint4 &h0, const uint4 &h1, int lane) {
-    const uint8_t *p = reinterpret_cast<const uint8_t *>(planes) + (((((uint64_t)h1.y) << 32) | (uint64_t)h1.x) << 8);
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(planes) + (((((uint64_t)h1.y) << 32) | (uint64_t)h1.x) << 5);
     ChunkRaw c;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const uint32_t w = (h0.w >> (3 * a)) & 7u;
-        c.a[a] = ld_axis(p, w, lane);
-        p += 256u * w;
+        const uint32_t b = (h0.w >> (6 * a)) & 63u;
+        c.a[a] = ld_axis(p, b, lane);
+        p += 32u * b;
     }
     return c;
 }
 __device__ __forceinline__ void unpack_chunk(const ChunkRaw &c, uint32_t widths, uint32_t bx, uint32_t by, uint32_t bz, float4 &X,
-                                             float4 &Y, float4 &Z) {
-    // the width combinations of ordered clouds first, each one compare away from straight-line code: the
-    // per-axis chains cost ~12 scalar instructions per axis, and the kernel is bound by instruction issue
-    constexpr uint32_t k333 = 3u | (3u << 3) | (3u << 6), k033 = (3u << 3) | (3u << 6), k303 = 3u | (3u << 6), k330 = 3u | (3u << 3);
-    if (widths == k333) {
-        X = unpack_axis(c.a[0], 3u, bx), Y = unpack_axis(c.a[1], 3u, by), Z = unpack_axis(c.a[2], 3u, bz);
-    } else if (widths == k033) {
-        X = unpack_axis(c.a[0], 0u, bx), Y = unpack_axis(c.a[1], 3u, by), Z = unpack_axis(c.a[2], 3u, bz);
-    } else if (widths == k303) {
-        X = unpack_axis(c.a[0], 3u, bx), Y = unpack_axis(c.a[1], 0u, by), Z = unpack_axis(c.a[2], 3u, bz);
-    } else if (widths == k330) {
-        X = unpack_axis(c.a[0], 3u, bx), Y = unpack_axis(c.a[1], 3u, by), Z = unpack_axis(c.a[2], 0u, bz);
+                                             float4 &Y, float4 &Z, int lane) {
+    if (!(widths & kPackWideFlag)) {  // no axis of the chunk needs all 32 bits (the usual case)
+        // (a constant axis -- a wall of the synthetic room, 30 % of its axis blocks -- skips the fifteen instructions)
+        const uint32_t wx = widths & 63u, wy = (widths >> 6) & 63u, wz = (widths >> 12) & 63u;
+        X = wx ? unpack_axis_narrow(c.a[0], wx, bx, lane) : make_float4(__uint_as_float(bx), __uint_as_float(bx), __uint_as_float(bx), __uint_as_float(bx));
+        Y = wy ? unpack_axis_narrow(c.a[1], wy, by, lane) : make_float4(__uint_as_float(by), __uint_as_float(by), __uint_as_float(by), __uint_as_float(by));
+        Z = wz ? unpack_axis_narrow(c.a[2], wz, bz, lane) : make_float4(__uint_as_float(bz), __uint_as_float(bz), __uint_as_float(bz), __uint_as_float(bz));
     } else {
-        X = unpack_axis(c.a[0], widths & 7u, bx);
-        Y = unpack_axis(c.a[1], (widths >> 3) & 7u, by);
-        Z = unpack_axis(c.a[2], (widths >> 6) & 7u, bz);
+        X = unpack_axis(c.a[0], widths & 63u, bx, lane);
+        Y = unpack_axis(c.a[1], (widths >> 6) & 63u, by, lane);
+        Z = unpack_axis(c.a[2], (widths >> 12) & 63u, bz, lane);
     }
 }
 
@@ -856,24 +858,32 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
         return (q < R && c < nchunks) ? c : nchunks;
     };
     // one quad (four points per lane) of the wave; every exit is wave-uniform
-    // the three matrix rows for the four points of a lane (render.cu:33-40); X, Y, Z are dead afterwards
-    struct Rows { float rx[4], ry[4], rz[4]; };
+    // the matrix rows for the four points of a lane (render.cu:33-40).  Only the r.z row before the first exit: about
+    // half of the chunks of an indoor view lie behind the camera, and the r.x / r.y rows are a third of what a chunk
+    // that leaves early costs
+    struct Rows { float4 X, Y, Z; float rz[4]; };
     auto project_rows = [&](const float4 &X, const float4 &Y, const float4 &Z, Rows &r) {
         const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+        r.X = X, r.Y = Y, r.Z = Z;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            r.rz[k] = f_add(fmaf(P.m[10], zs[k], fmaf(P.m[9], ys[k], f_mul(P.m[8], xs[k]))), P.m[11]);
-            r.rx[k] = f_add(fmaf(P.m[2], zs[k], fmaf(P.m[1], ys[k], f_mul(P.m[0], xs[k]))), P.m[3]);
-            r.ry[k] = f_add(fmaf(P.m[6], zs[k], fmaf(P.m[5], ys[k], f_mul(P.m[4], xs[k]))), P.m[7]);
-        }
+        for (int k = 0; k < 4; ++k) r.rz[k] = f_add(fmaf(P.m[10], zs[k], fmaf(P.m[9], ys[k], f_mul(P.m[8], xs[k]))), P.m[11]);
     };
     uint32_t n_colour = 0;  // chunks of this wave whose colours were loaded (frame statistics)
     auto do_quad = [&](uint32_t i, bool live, const Rows &r) {
-        const float *rx = r.rx, *ry = r.ry, *rz = r.rz;
-        // (the kernel is bound by instruction issue once the coordinates are packed: one max3 + max + compare
-        // instead of four compares and their combination; fmaxf skips NaNs, and an all-NaN quad compares false)
+        const float *rz = r.rz;
+        // (one max3 + max + compare instead of four compares and their combination; fmaxf skips NaNs, and an
+        // all-NaN quad compares false)
         const bool front = live && (fmaxf(fmaxf(rz[0], rz[1]), fmaxf(rz[2], rz[3])) > 0.0f);  // render.cu:63
         if (__ballot(front) == 0ull) return;
+        float rx[4], ry[4];
+        {
+            const float xs[4] = {r.X.x, r.X.y, r.X.z, r.X.w}, ys[4] = {r.Y.x, r.Y.y, r.Y.z, r.Y.w}, zs[4] = {r.Z.x, r.Z.y, r.Z.z, r.Z.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                rx[k] = f_add(fmaf(P.m[2], zs[k], fmaf(P.m[1], ys[k], f_mul(P.m[0], xs[k]))), P.m[3]);
+                ry[k] = f_add(fmaf(P.m[6], zs[k], fmaf(P.m[5], ys[k], f_mul(P.m[4], xs[k]))), P.m[7]);
+            }
+        }
         bool maybe[4], any = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1068,15 +1078,13 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
                 continue;
             }
 #endif
-            unpack_chunk(raw, ww, bx, by, bz, X, Y, Z);
+            unpack_chunk(raw, ww, bx, by, bz, X, Y, Z, lane);
             project_rows(X, Y, Z, r);
             fetch_planes();
             fetch_hdr(q + 2);
 #ifdef RTR_EXPERIMENT
             if (RTR_XP(256)) {  // ... + decode + the three matrix rows
-                xp_sink ^= __float_as_uint(r.rx[0]) ^ __float_as_uint(r.ry[1]) ^ __float_as_uint(r.rz[2]) ^ __float_as_uint(r.rx[3]) ^
-                           __float_as_uint(r.rz[0]) ^ __float_as_uint(r.ry[2]) ^ __float_as_uint(r.rx[1]) ^ __float_as_uint(r.rz[3]) ^
-                           __float_as_uint(r.ry[0]) ^ __float_as_uint(r.rx[2]) ^ __float_as_uint(r.rz[1]) ^ __float_as_uint(r.ry[3]);
+                xp_sink ^= __float_as_uint(r.rz[0]) ^ __float_as_uint(r.rz[1]) ^ __float_as_uint(r.rz[2]) ^ __float_as_uint(r.rz[3]);
                 continue;
             }
 #endif
@@ -1166,7 +1174,7 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
                     const uint32_t cc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(i >> 6));
                     const uint4 h0 = pk_hdr[2 * (size_t)cc], h1 = pk_hdr[2 * (size_t)cc + 1];
                     const ChunkRaw raw = load_chunk(pk_planes, h0, h1, lane);
-                    unpack_chunk(raw, h0.w, h0.x, h0.y, h0.z, X, Y, Z);
+                    unpack_chunk(raw, h0.w, h0.x, h0.y, h0.z, X, Y, Z, lane);
                 } else {
                     X = ld_stream(x4 + ic), Y = ld_stream(y4 + ic), Z = ld_stream(z4 + ic);
                 }
@@ -1546,24 +1554,33 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
             const uint32_t px = (uint32_t)(e >> 24) & 511u;
             return pb + ((px >> 5) << g.tw_shift) + (px & 31u);
         };
+        // (Both passes first read the LDS depth under ALL of the thread's entries, then work through them: the reads of
+        // a pass are then in flight together instead of one dependent LDS round trip per entry -- the compiler cannot
+        // hoist them itself past the atomics on the same array.  A stale early-z value is >= the true minimum: it
+        // can only cause a redundant atomic.)
         auto min_runs = [&](auto per_tag) {
             constexpr int PER = decltype(per_tag)::value;
+            uint32_t pix[kTileBatch], cur[kTileBatch];
+#pragma unroll
+            for (int k = 0; k < kTileBatch; ++k) pix[k] = pixel_of(r[k], stream_pb(k / PER));
+#pragma unroll
+            for (int k = 0; k < kTileBatch; ++k) cur[k] = __hip_atomic_load(&s_mem[pix[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
             for (int k0 = 0; k0 < kTileBatch; k0 += PER) {
-                const uint32_t pb = stream_pb(k0 / PER);
-                uint32_t run_p = pixel_of(r[k0], pb), run_d = (uint32_t)(r[k0] >> 33);
+                uint32_t run_p = pix[k0], run_d = (uint32_t)(r[k0] >> 33), run_c = cur[k0];
 #pragma unroll
                 for (int j = 1; j < PER; ++j) {
-                    const uint32_t pj = pixel_of(r[k0 + j], pb), dj = (uint32_t)(r[k0 + j] >> 33);
+                    const uint32_t pj = pix[k0 + j], dj = (uint32_t)(r[k0 + j] >> 33);
                     if (pj != run_p) {
-                        if (run_d < __hip_atomic_load(&s_mem[run_p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMin(&s_mem[run_p], run_d);
+                        if (run_d < run_c) atomicMin(&s_mem[run_p], run_d);
                         run_p = pj;
                         run_d = dj;
+                        run_c = cur[k0 + j];
                     } else {
                         run_d = dj < run_d ? dj : run_d;
                     }
                 }
-                if (run_d < __hip_atomic_load(&s_mem[run_p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMin(&s_mem[run_p], run_d);
+                if (run_d < run_c) atomicMin(&s_mem[run_p], run_d);
             }
         };
         auto acc_runs = [&](auto per_tag, bool packed) {
@@ -1577,20 +1594,24 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
                     atomicAdd(s_acc64 + 2 * p + 1, ((v >> 32) & 0xFFFFull) | ((v >> 48) << 32));
                 }
             };
-            auto value_of = [&](unsigned long long e, uint32_t p) -> unsigned long long {
-                const float m = __uint_as_float(s_mem[p]);  // s_depth
-                if (__uint_as_float((uint32_t)(e >> 33)) > f_add(m, window)) return 0ull;  // render.cu:106, then :125-128
+            uint32_t pix[kTileBatch];
+            float m[kTileBatch];
+#pragma unroll
+            for (int k = 0; k < kTileBatch; ++k) pix[k] = pixel_of(r[k], stream_pb(k / PER));
+#pragma unroll
+            for (int k = 0; k < kTileBatch; ++k) m[k] = __uint_as_float(s_mem[pix[k]]);  // s_depth: final since the barrier
+            auto value_of = [&](unsigned long long e, float mk) -> unsigned long long {
+                if (__uint_as_float((uint32_t)(e >> 33)) > f_add(mk, window)) return 0ull;  // render.cu:106, then :125-128
                 return (e & 0xFFull) | (((e >> 8) & 0xFFull) << 16) | (((e >> 16) & 0xFFull) << 32) | (1ull << 48);
             };
 #pragma unroll
             for (int k0 = 0; k0 < kTileBatch; k0 += PER) {
-                const uint32_t pb = stream_pb(k0 / PER);
-                uint32_t run_p = pixel_of(r[k0], pb);
-                unsigned long long run_v = value_of(r[k0], run_p);
+                uint32_t run_p = pix[k0];
+                unsigned long long run_v = value_of(r[k0], m[k0]);
 #pragma unroll
                 for (int j = 1; j < PER; ++j) {
-                    const uint32_t pj = pixel_of(r[k0 + j], pb);
-                    const unsigned long long vj = value_of(r[k0 + j], pj);
+                    const uint32_t pj = pix[k0 + j];
+                    const unsigned long long vj = value_of(r[k0 + j], m[k0 + j]);
                     if (pj != run_p) {
                         flush(run_p, run_v);
                         run_p = pj;
@@ -1902,13 +1923,14 @@ __global__ __launch_bounds__(kBlock) void k_pack_measure(const uint4 *__restrict
         if (lane == 0) {
             uint32_t w[3], base[3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {  // bytes below the common prefix of the chunk's 256 bit patterns
-                const uint32_t r = diff[a];
-                w[a] = r == 0u ? 0u : (r < 0x100u ? 1u : (r < 0x10000u ? 2u : (r < 0x1000000u ? 3u : 4u)));
-                base[a] = w[a] == 4u ? 0u : (first[a] >> (8u * w[a])) << (8u * w[a]);
+            for (int a = 0; a < 3; ++a) {  // bits below the common prefix of the chunk's 256 bit patterns
+                const uint32_t nb = diff[a] == 0u ? 0u : 32u - (uint32_t)__clz((int)diff[a]);
+                w[a] = nb > kPackMaxBits ? 32u : nb;  // (a lane's shift + 4 b bits must fit its 16-byte load)
+                base[a] = w[a] == 32u ? 0u : (first[a] >> w[a]) << w[a];
             }
-            hdr[2 * c] = make_uint4(base[0], base[1], base[2], w[0] | (w[1] << 3) | (w[2] << 6));
-            chunk_planes[c] = w[0] + w[1] + w[2];
+            const uint32_t wide = (w[0] == 32u || w[1] == 32u || w[2] == 32u) ? kPackWideFlag : 0u;
+            hdr[2 * c] = make_uint4(base[0], base[1], base[2], w[0] | (w[1] << 6) | (w[2] << 12) | wide);
+            chunk_planes[c] = w[0] + w[1] + w[2];  // in units of 32 bytes
         }
     }
 }
@@ -1933,25 +1955,43 @@ __global__ __launch_bounds__(512) void k_pack_scan(const uint32_t *__restrict__ 
 __global__ __launch_bounds__(kBlock) void k_pack_write(const uint4 *__restrict__ x4, const uint4 *__restrict__ y4,
                                                        const uint4 *__restrict__ z4, uint64_t n4, const uint4 *__restrict__ hdr,
                                                        uint32_t *__restrict__ planes) {
+    // (a one-off at upload.)  An axis block is assembled in LDS -- every lane ORs its 4 b bits in at bit 4 b l --
+    // and leaves as whole dwords, coalesced.
+    __shared__ uint32_t s_blk[kBlock / 64][256 + 4];
     const uint64_t nchunks = (n4 + 63) / 64;
     const int lane = threadIdx.x & 63;
+    uint32_t *const blk = s_blk[threadIdx.x >> 6];
     for (uint64_t c = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6; c < nchunks; c += ((uint64_t)gridDim.x * kBlock) >> 6) {
         uint32_t v[3][4];
         chunk_bits(x4, y4, z4, n4, c, lane, v);
         const uint4 h0 = hdr[2 * c], h1 = hdr[2 * c + 1];
-        uint32_t *p = planes + (((((uint64_t)h1.y) << 32) | (uint64_t)h1.x) << 6);
-#pragma unroll
+        uint32_t *p = planes + (((((uint64_t)h1.y) << 32) | (uint64_t)h1.x) << 3);
+#pragma unroll 1
         for (int a = 0; a < 3; ++a) {
-            const uint32_t w = (h0.w >> (3 * a)) & 7u;
-            // the lane's four values, low w bytes each, back to back: w dwords at dword w * lane of the axis block
+            const uint32_t b = (h0.w >> (6 * a)) & 63u;  // wave-uniform
+            if (b == 0u) continue;
+            const uint32_t ndw = 8u * b;  // dwords of the block
+            for (uint32_t j = (uint32_t)lane; j < ndw + 4u; j += 64u) blk[j] = 0u;
+            __builtin_amdgcn_wave_barrier();
             unsigned __int128 blob = 0;
+            const uint32_t m = b == 32u ? 0xFFFFFFFFu : ((1u << b) - 1u);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t e = w == 4u ? v[a][k] : (v[a][k] & ((1u << (8u * w)) - 1u));
-                blob |= (unsigned __int128)e << (8u * w * (uint32_t)k);
+            for (int k = 0; k < 4; ++k) blob |= (unsigned __int128)(v[a][k] & m) << (b * (uint32_t)k);
+            const uint32_t bit = 4u * b * (uint32_t)lane, dw = bit >> 5, sh = bit & 31u;
+            // (the blob, shifted by sh < 32 bits, spans at most five dwords)
+            const uint32_t lo32[4] = {(uint32_t)blob, (uint32_t)(blob >> 32), (uint32_t)(blob >> 64), (uint32_t)(blob >> 96)};
+            uint32_t carry = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t w = (lo32[j] << sh) | carry;
+                carry = sh ? (lo32[j] >> (32u - sh)) : 0u;
+                if (w) atomicOr(&blk[dw + j], w);
             }
-            for (uint32_t j = 0; j < w; ++j) p[w * (uint32_t)lane + j] = (uint32_t)(blob >> (32u * j));
-            p += 64u * w;
+            if (carry) atomicOr(&blk[dw + 4], carry);
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j = (uint32_t)lane; j < ndw; j += 64u) p[j] = blk[j];
+            __builtin_amdgcn_wave_barrier();
+            p += ndw;
         }
     }
 }
@@ -1967,7 +2007,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_verify(const uint4 *__restrict_
         const uint4 h0 = hdr[2 * c], h1 = hdr[2 * c + 1];
         const ChunkRaw raw = load_chunk(planes, h0, h1, lane);
         float4 X, Y, Z;
-        unpack_chunk(raw, h0.w, h0.x, h0.y, h0.z, X, Y, Z);
+        unpack_chunk(raw, h0.w, h0.x, h0.y, h0.z, X, Y, Z, lane);
         const uint32_t got[3][4] = {{__float_as_uint(X.x), __float_as_uint(X.y), __float_as_uint(X.z), __float_as_uint(X.w)},
                                     {__float_as_uint(Y.x), __float_as_uint(Y.y), __float_as_uint(Y.z), __float_as_uint(Y.w)},
                                     {__float_as_uint(Z.x), __float_as_uint(Z.y), __float_as_uint(Z.z), __float_as_uint(Z.w)}};

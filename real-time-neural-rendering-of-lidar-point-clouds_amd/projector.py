@@ -150,6 +150,24 @@ class Projector:
         fn = self._lib.rtr_project_filtered if filtered else self._lib.rtr_project
         self._chk(fn(self._ctx, _vp(P), _vp(img), _vp(depth)))
 
+    # -- asynchronous host outputs (rtr.h section 4b)
+    def host_output_buffers(self, slot):
+        """-> (img uint8 [H,W,3], depth float32 [H,W]): numpy views of the library's pinned buffers of `slot`
+        (valid until the next set_resolution; filled by project_async, complete after wait_outputs)."""
+        pi, pd = C.c_void_p(), C.c_void_p()
+        self._chk(self._lib.rtr_host_output_buffers(self._ctx, int(slot), C.byref(pi), C.byref(pd)))
+        img = np.ctypeslib.as_array(C.cast(pi, C.POINTER(C.c_uint8)), shape=(self.H, self.W, 3))
+        depth = np.ctypeslib.as_array(C.cast(pd, C.POINTER(C.c_float)), shape=(self.H, self.W))
+        return img, depth
+
+    def project_async(self, P, slot, filtered=False):
+        """Renders a frame and queues the copies of depth + image into the pinned buffers of `slot`; does not wait."""
+        P = self._P(P)
+        self._chk(self._lib.rtr_project_async(self._ctx, _vp(P), int(slot), 1 if filtered else 0))
+
+    def wait_outputs(self, slot=-1):
+        self._chk(self._lib.rtr_wait(self._ctx, int(slot)))
+
     def render(self, P, with_filter=False):
         P = self._P(P)
         self._chk(self._lib.rtr_render(self._ctx, _vp(P), 1 if with_filter else 0))

@@ -389,16 +389,19 @@ def test_pack_option(pkg, orc):
                 assert np.array_equal(img, ref["img"]), (scene, pack)
                 back, cols = p.download_points()
                 assert np.array_equal(back.view(np.uint32), xyzw.view(np.uint32)) and np.array_equal(cols, rgba)
-        # every width class in one cloud: constant axes, 1-, 2-, 3-byte ranges, sign changes, NaN / inf / -0
+        # every width in one cloud: constant axes, 1 .. 25 differing low bits, the ranges that fall back to 32 bits,
+        # sign changes, NaN / inf / -0 (axis a of chunk c spans 2^((c + 7 a) % 33) bit patterns)
         rng = np.random.default_rng(8)
-        m = 256 * 40 + 77
+        m = 256 * 70 + 77
         xyz = np.empty((m, 3), np.float32)
-        base = np.float32(2.0).view(np.uint32)
+        base = int(np.float32(2.0).view(np.uint32))
         for c in range(0, m, 256):
             k = min(256, m - c)
             for a in range(3):
-                span = [1, 200, 60000, 1 << 23, 1 << 31][(c // 256 + a) % 5]
-                xyz[c:c + k, a] = (base + rng.integers(0, span, size=k, dtype=np.uint64).astype(np.uint32)).view(np.float32)
+                span = 1 << ((c // 256 + 7 * a) % 33)
+                v = (base + rng.integers(0, span, size=k, dtype=np.uint64)) & 0xFFFFFFFF
+                v[0], v[-1] = base & 0xFFFFFFFF, (base + span - 1) & 0xFFFFFFFF  # (the whole range is in use)
+                xyz[c:c + k, a] = v.astype(np.uint32).view(np.float32)
         xyz[5, 0], xyz[6, 1], xyz[7, 2], xyz[300, 0] = np.nan, np.inf, -0.0, -1.5
         xyzw, rgba = cloud(xyz, rng.integers(0, 256, size=(m, 3), dtype=np.uint8))
         p.set_option("pack", 2)
