@@ -55,7 +55,8 @@ public:
             }
         }
         check(nullptr, rtr_create(&ctx_, device));
-        check(ctx_, rtr_set_option(ctx_, "auto_reorder", 1));  // one-off Morton sort: the grid's blocks are unordered inside
+        // (the library's default upload policy: the point order is measured and the cloud Morton-sorted once when its
+        // 256-point chunks are not compact -- the grid's 0.25 m blocks are unordered inside -- then packed losslessly)
         check(ctx_, rtr_upload_points(ctx_, xyzw.data(), 16, rgba.data(), 4, xyzw.size() / 4));
 #ifdef RTR_WITH_TORCH
         load_model(device);

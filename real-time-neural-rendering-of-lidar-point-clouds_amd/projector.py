@@ -283,8 +283,9 @@ class ProjectCloud:
     instead of a file."""
 
     def __init__(self, vertices, colors, modelFilename="", device=0, reorder=True):
-        """reorder: Morton-sort the cloud once after the upload (the grid's 0.25 m blocks are
-        unordered inside; frames do not depend on the point order)."""
+        """reorder: True keeps the library's default upload policy (the cloud is Morton-sorted once when its
+        256-point chunks are not spatially compact -- the grid's 0.25 m blocks are unordered inside); False never
+        sorts.  Frames do not depend on the point order."""
         self.modelFilename = modelFilename
         self.model = None
         self._device = device
@@ -298,7 +299,8 @@ class ProjectCloud:
                                         "camera resolution first)" % path)
             self.model = torch.jit.load(path, map_location="cuda:%d" % device)
         self._p = Projector(device)
-        self._p.set_option("auto_reorder", 1 if reorder else 0)
+        if not reorder:
+            self._p.set_option("auto_reorder", 0)
         self._p.upload_points(vertices, colors)
 
     def set_model(self, model):

@@ -492,6 +492,46 @@ def test_hot_tile_is_split_in_the_binned_form(pkg, orc, projector):
         assert np.array_equal(img, ri), k
 
 
+def test_async_host_outputs_match_the_synchronous_calls(pkg, orc, projector):
+    """rtr_project_async / rtr_wait (rtr.h 4b): frames queued back to back into the two pinned output slots -- frame k's
+    device-to-host copies run beside frame k + 1's kernels -- equal the frames of the synchronous calls and the
+    oracle, filtered or not, also when a slot is reused without an explicit wait in between."""
+    W, H, n = 640, 480, 300_000
+    xyzw, rgba = orc.generate("room_shell", 91, 0, n, n)
+    projector.upload_points(xyzw, rgba)
+    projector.set_resolution(W, H)
+    poses = [pkg.orbit_projection(k, W, H) for k in (3, 140, 277, 410, 520, 731)]
+    bufs = [projector.host_output_buffers(s) for s in range(2)]
+    for filtered in (False, True):
+        refs = []
+        for P in poses:
+            ref = orc.project(xyzw, rgba, P, W, H)
+            rd, ri = ref["depth_bits"], ref["img"]
+            if filtered:
+                rf = orc.filter(rd, ri)
+                rd, ri = rf["depth"].view(np.uint32), rf["img"]
+            refs.append((rd, ri))
+        # two frames in flight, then collect: slots alternate
+        for k0 in range(0, len(poses), 2):
+            projector.project_async(poses[k0], 0, filtered)
+            projector.project_async(poses[k0 + 1], 1, filtered)
+            for s in range(2):
+                projector.wait_outputs(s)
+                img, depth = bufs[s]
+                assert np.array_equal(depth.view(np.uint32), refs[k0 + s][0]), (filtered, k0 + s)
+                assert np.array_equal(img, refs[k0 + s][1]), (filtered, k0 + s)
+        # a slot reused while its previous frame may still be on its way: the library orders the two itself
+        for k in range(len(poses)):
+            projector.project_async(poses[k], k & 1, filtered)
+        projector.wait_outputs()
+        for s, k in ((0, len(poses) - 2), (1, len(poses) - 1)):
+            assert np.array_equal(bufs[s][1].view(np.uint32), refs[k][0]) and np.array_equal(bufs[s][0], refs[k][1])
+        img_s, depth_s = projector.project(poses[-1], filtered=filtered)
+        assert np.array_equal(depth_s.view(np.uint32), bufs[1][1].view(np.uint32)) and np.array_equal(img_s, bufs[1][0])
+    with pytest.raises(pkg._lib.RtrError):
+        projector.project_async(poses[0], 2)
+
+
 def test_tile_store_error_reaches_the_caller(pkg, orc, projector):
     """A tile store that has to drop entries must never hand back a wrong frame as RTR_OK.  Option "debug_dyn_cap"
     shrinks the pool of dynamic stream extents so that a tile with more than 4096 entries overflows it (error
