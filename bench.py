@@ -56,10 +56,13 @@ def parse():
                     help="N>1: frames in flight per rank (2 = frame k's RCCL exchange overlaps frame k+1's kernels)")
     ap.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2, 3],
                     help="N=1: independent frames alternate between this many contexts / HIP streams")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "collective", "p2p"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "collective", "p2p", "owned"],
                     help="N > 1: 'collective' = torch.distributed (RCCL) on the library's buffers; 'p2p' = the library's "
-                         "hand-written exchange over hipIpc-mapped peer buffers; 'auto' (default) times the collectives, "
-                         "then the p2p form (verified against the collectives before and after), and reports the faster")
+                         "hand-written MIN / SUM exchange over hipIpc-mapped peer buffers; 'owned' = the owner-computes "
+                         "form (every tile produced once, by a rank that has points in it, over the entries of all "
+                         "occupying ranks; the frame's owner rotates); 'auto' (default) times the collectives, then the "
+                         "two hand-written forms (each verified against the collectives before and after), and reports "
+                         "the fastest clean one")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + several ranks on ONE GPU is a rehearsal of the N>1 logic")
     ap.add_argument("--force-exchange", action="store_true",
@@ -392,11 +395,12 @@ def main():
     def run_exchange_forms(setup, rs, steps, warmup):
         """The timed run, with the p2p form tried after the collectives when asked for (N > 1)."""
         info = None
-        if multi and args.exchange == "p2p":
-            rs = setup.renderers(colour, "p2p")
+        if multi and args.exchange in ("p2p", "owned"):
+            rs = setup.renderers(colour, args.exchange)
         dt_, timing_ = setup.timed_run(rs, steps, warmup)
-        if multi and args.exchange == "p2p":
-            info = {"used": "p2p" if all(r.exchange == "p2p" for r in rs) else "collective (p2p dropped)",
+        if multi and args.exchange in ("p2p", "owned"):
+            info = {"used": args.exchange if all(r.exchange == args.exchange for r in rs)
+                    else "collective (%s dropped)" % args.exchange,
                     "p2p_note": [r.p2p_note for r in rs if r.p2p_note]}
         elif multi and args.exchange == "auto":
             # The hand-written peer-to-peer exchange, tried after the collectives have been measured:
@@ -427,6 +431,33 @@ def main():
             if clean and dt2 is not None and dt2 < dt_:  # both are max-over-ranks: every rank decides alike
                 dt_, timing_ = dt2, timing2
                 info["used"] = "p2p"
+            # The owner-computes form: no MIN / SUM exchange, every tile produced once; the frame's owner rotates over
+            # the ranks (rank k mod N ends with frame k).  Checked the same way, with rank 0 owning the checked frame.
+            try:
+                own_r = setup.renderers(colour, "owned")
+                dt3, timing3 = setup.timed_run(own_r, steps, warmup)
+                clean3 = all(r.exchange == "owned" for r in own_r) and all(pj.p2p_timeouts() == 0 for pj in setup.projs)
+                if clean3:
+                    k_chk = warmup + steps - 1
+                    for r in own_r:
+                        r.fixed_owner = 0
+                    setup.render(own_r, 0, poses[k_chk]); setup.sync()
+                    d_o, i_o = setup.locals_[0].depth_tensor().clone(), setup.locals_[0].image_tensor().clone()
+                    setup.render(rs, 0, poses[k_chk]); setup.sync()
+                    clean3 = rank != 0 or bool(torch.equal(d_o, setup.locals_[0].depth_tensor()) and
+                                               torch.equal(i_o, setup.locals_[0].image_tensor()))
+                note3 = [r.p2p_note for r in own_r if r.p2p_note]
+            except Exception as exc:  # noqa: BLE001
+                clean3, dt3, timing3, note3 = False, None, None, ["%s" % exc]
+            clean3 = all_ranks(clean3)
+            info["owned_clean_on_all_ranks"] = clean3
+            if dt3 is not None:
+                info["owned_ms_per_step"] = dt3 / steps * 1e3
+            if note3:
+                info["owned_note"] = note3
+            if clean3 and dt3 is not None and dt3 < dt_:
+                dt_, timing_ = dt3, timing3
+                info["used"] = "owned"
         return dt_, timing_, info
 
     def kernel_table(timing_):
@@ -699,7 +730,10 @@ def main():
                        "points_total": total, "points_per_gpu": n_local, "scene": args.scene,
                        "resolution": [W, H], "prefilter": with_filter,
                        **({"options": args.set} if args.set else {}),
-                       "parallelism": (("point-shard x%d, hand-written peer-to-peer exchange over hipIpc-mapped buffers: "
+                       "parallelism": (("point-shard x%d, owner-computes tiles over hipIpc-mapped tile stores (no MIN / SUM "
+                                        "exchange; the frame's owner rotates), %d frames in flight" % (world, depth_k))
+                                       if (exchange_info or {}).get("used") == "owned" else
+                                       ("point-shard x%d, hand-written peer-to-peer exchange over hipIpc-mapped buffers: "
                                         "MIN(depth), SUM(accum) + slice resolve, %d frames in flight" % (world, depth_k))
                                        if (exchange_info or {}).get("used") == "p2p" else
                                        ("point-shard x%d, %s all-reduce MIN(depth) + %s SUM(accum), %d frames in "

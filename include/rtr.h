@@ -224,6 +224,10 @@ typedef struct rtr_p2p_handles {
     unsigned char depth[64], accum[64], image[64], reduced[64], flags[64], tiles[64];
     /* one hipIpcMemHandle_t each: the depth buffer and accumulators, exchange copies of the resolved
      * image and the reduced depth, the barrier flags, the per-tile occupancy bitmap */
+    unsigned char store_meta[64], store_ext0[64], store_dyn[64];
+    /* ... and this rank's tile store (stream lengths and extent directory, static extents, dynamic extent pool): the
+     * owner-computes form reads the peers' entries out of it.  The store is sized by the resident cloud: export (and
+     * open) again after rtr_upload_points / rtr_generate_synthetic. */
 } rtr_p2p_handles;
 int rtr_p2p_export(rtr_ctx *ctx, rtr_p2p_handles *mine);
 int rtr_p2p_open(rtr_ctx *ctx, int rank, int world, const rtr_p2p_handles *all /* [world] */);
@@ -238,6 +242,14 @@ int rtr_p2p_sum_resolve(rtr_ctx *ctx);
  * this rank's partial sums, and in the tile-binned form only under the screen tiles that contain
  * points of this rank (the peers read nothing else: tiles without local points are not written). */
 int rtr_p2p_render(rtr_ctx *ctx, const float P[16], int with_filter);
+/* The owner-computes form of the sharded frame (tile-binned mode): every screen tile is produced by ONE of the ranks
+ * that have points in it, which reads the other occupying ranks' entries out of their tile stores over xGMI and runs the
+ * fused per-tile z-buffer once -- no MIN / SUM exchange, no second tile pass, two barriers and at most six launches per
+ * frame.  Afterwards only rank `frame_owner` holds the GLOBAL frame (RTR_BUF_DEPTH / IMAGE and the prefilter's outputs:
+ * it collects the other ranks' tiles); the buffers of the other ranks hold their own tiles only.  All ranks must pass
+ * the same frame_owner; rotating it (frame k -> rank k mod world) spreads the collect + prefilter over the ranks, e.g.
+ * one U-Net consumer per GPU.  Tiles are not split over workgroups in this form (split_threshold is ignored). */
+int rtr_p2p_render_owned(rtr_ctx *ctx, const float P[16], int with_filter, int frame_owner);
 int rtr_p2p_status(rtr_ctx *ctx, uint32_t *barrier_timeouts);
 
 /* ---- 6. device-resident buffers (owned by the context, valid until the next

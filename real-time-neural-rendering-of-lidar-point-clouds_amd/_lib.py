@@ -23,12 +23,13 @@ SYMBOLS = [
     "rtr_timing_get", "rtr_set_option", "rtr_stream_probe", "rtr_resolve_range", "rtr_reorder_points", "rtr_reset_stream",
     "rtr_device_count", "rtr_p2p_export", "rtr_p2p_open", "rtr_p2p_close", "rtr_p2p_min_depth", "rtr_p2p_sum_resolve", "rtr_p2p_status",
     "rtr_p2p_render", "rtr_frame_stats", "rtr_get_option", "rtr_host_output_buffers", "rtr_project_async", "rtr_wait",
+    "rtr_p2p_render_owned",
 ]
 
 RTR_OK, RTR_ERR_INVALID, RTR_ERR_HIP, RTR_ERR_NO_OUTPUT, RTR_ERR_UNSUPPORTED, RTR_ERR_INTERNAL = 0, -1, -2, -3, -4, -5
 BUF_DEPTH, BUF_ACCUM, BUF_IMAGE, BUF_TENSOR, BUF_MASK, BUF_MINMAX = range(6)
 K_CLEAR, K_MIN_DEPTH, K_ACCUMULATE, K_RESOLVE, K_FILTER, K_PROBE, K_TILE, K_BIN = range(8)
-P2P_HANDLES_BYTES = 6 * 64  # sizeof(rtr_p2p_handles)
+P2P_HANDLES_BYTES = 9 * 64  # sizeof(rtr_p2p_handles)
 KERNEL_NAMES = ["clear", "min_depth", "accumulate", "resolve", "filter", "probe", "tile", "bin"]
 SCENES = {"uniform_box": 0, "room_shell": 1}
 EMPTY_DEPTH = 0x7F7FFFFF
@@ -107,6 +108,7 @@ def lib():
     L.rtr_p2p_sum_resolve.argtypes = [vp]
     L.rtr_p2p_status.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.rtr_p2p_render.argtypes = [vp, vp, i32]
+    L.rtr_p2p_render_owned.argtypes = [vp, vp, i32, i32]
     L.rtr_frame_stats.argtypes = [vp, vp]
     L.rtr_get_option.argtypes = [vp, C.c_char_p, C.POINTER(i32)]
     L.rtr_host_output_buffers.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]

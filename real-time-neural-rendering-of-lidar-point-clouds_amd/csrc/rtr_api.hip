@@ -105,8 +105,9 @@ struct rtr_ctx {
         bool acc_from_bins = false;       // the last accumulate pass used exactly those bins
         uint32_t *status_host = nullptr;  // mapped host word: barrier timeouts
         uint32_t *status_dev = nullptr;
-        rtr::PeerSet depth{}, accum{}, image{}, reduced{}, flags_of{}, occ_of{};
-        void *opened[6][RTR_P2P_MAX_RANKS] = {};
+        rtr::PeerSet depth{}, accum{}, image{}, reduced{}, flags_of{}, occ_of{}, meta_of{}, ext0_of{}, dyn_of{};
+        rtr::OwnedTab *tab = nullptr;     // device copy of the peers' tile-store / frame-buffer mappings (owner-computes form)
+        void *opened[9][RTR_P2P_MAX_RANKS] = {};
         int rank = 0, world = 0;
         uint32_t seq = 0;
         bool open = false;
@@ -188,6 +189,7 @@ void p2p_release(rtr_ctx *c) {  // the peers' mappings and this rank's exchange 
     dfree(q.flags);
     dfree(q.occ);
     dfree(q.occ_all);
+    dfree(q.tab);
     q.open = false;
     q.world = 0;
     q.seq = 0;
@@ -232,6 +234,7 @@ void free_frame(rtr_ctx *c) {
 }
 
 void free_lists(rtr_ctx *c) {  // the dynamic extent pools (sized by the point count)
+    if (c->p2p.open || c->p2p.red) p2p_release(c);  // (the peers map this rank's pool: they must re-open after a new cloud)
     for (auto &f : c->fs) {
         dfree(f.dyn);
         f.dyn_cap = 0;
@@ -299,6 +302,7 @@ int ensure_tiles(rtr_ctx *c, hipStream_t s) {
 int ensure_lists(rtr_ctx *c) {
     auto &f = c->F();
     if (f.dyn && f.pool_n == c->n) return RTR_OK;
+    if (c->p2p.open || c->p2p.red) p2p_release(c);  // (the peers map this pool: export / open again after a new cloud)
     dfree(f.dyn);
     c->list_valid = false;
     f.dyn_cap = 2 * c->n + 64;
@@ -1309,11 +1313,18 @@ int rtr_p2p_export(rtr_ctx *c, rtr_p2p_handles *mine) {
     static_assert(sizeof(hipIpcMemHandle_t) <= 64, "handle block too small");
     DevGuard g(c->device);
     HIP_TRY(c, sync_streams(c));
+    // (the owner-computes form reads the peers' tile stores: allocate this rank's now -- it is sized by the cloud)
+    c->cur = 0;
+    if (int rc = ensure_lists(c)) return rc;
+    if (int rc = ensure_tiles(c, c->stream)) return rc;
     if (int rc = p2p_alloc(c)) return rc;
+    HIP_TRY(c, sync_streams(c));
     memset(mine, 0, sizeof *mine);
-    void *bufs[6] = {c->depth, c->acc, c->p2p.ximg, c->p2p.red, c->p2p.flags, c->p2p.occ};
-    unsigned char *dst[6] = {mine->depth, mine->accum, mine->image, mine->reduced, mine->flags, mine->tiles};
-    for (int k = 0; k < 6; ++k) {
+    void *bufs[9] = {c->depth, c->acc, c->p2p.ximg, c->p2p.red, c->p2p.flags, c->p2p.occ,
+                     c->F().store.meta, c->F().store.ext0, c->F().dyn};
+    unsigned char *dst[9] = {mine->depth, mine->accum, mine->image, mine->reduced, mine->flags, mine->tiles,
+                             mine->store_meta, mine->store_ext0, mine->store_dyn};
+    for (int k = 0; k < 9; ++k) {
         hipIpcMemHandle_t h;
         HIP_TRY(c, hipIpcGetMemHandle(&h, bufs[k]));
         memcpy(dst[k], &h, sizeof h);
@@ -1331,11 +1342,13 @@ int rtr_p2p_open(rtr_ctx *c, int rank, int world, const rtr_p2p_handles *all) {
     auto &q = c->p2p;
     NEED(c, q.red && q.ximg && q.flags && q.occ, "rtr_p2p_export has not been called for this resolution");
     NEED(c, !q.open, "already open (rtr_p2p_close first)");
-    rtr::PeerSet *sets[6] = {&q.depth, &q.accum, &q.image, &q.reduced, &q.flags_of, &q.occ_of};
-    void *own[6] = {c->depth, c->acc, q.ximg, q.red, q.flags, q.occ};
+    NEED(c, c->F().store.meta && c->F().store.ext0 && c->F().dyn, "the tile store changed since rtr_p2p_export (export again)");
+    rtr::PeerSet *sets[9] = {&q.depth, &q.accum, &q.image, &q.reduced, &q.flags_of, &q.occ_of, &q.meta_of, &q.ext0_of, &q.dyn_of};
+    void *own[9] = {c->depth, c->acc, q.ximg, q.red, q.flags, q.occ, c->F().store.meta, c->F().store.ext0, c->F().dyn};
     for (int r = 0; r < world; ++r) {
-        const unsigned char *src[6] = {all[r].depth, all[r].accum, all[r].image, all[r].reduced, all[r].flags, all[r].tiles};
-        for (int k = 0; k < 6; ++k) {
+        const unsigned char *src[9] = {all[r].depth, all[r].accum, all[r].image, all[r].reduced, all[r].flags, all[r].tiles,
+                                       all[r].store_meta, all[r].store_ext0, all[r].store_dyn};
+        for (int k = 0; k < 9; ++k) {
             if (r == rank) {
                 sets[k]->p[r] = own[k];
                 continue;
@@ -1352,6 +1365,18 @@ int rtr_p2p_open(rtr_ctx *c, int rank, int world, const rtr_p2p_handles *all) {
             q.opened[k][r] = ptr;
             sets[k]->p[r] = ptr;
         }
+    }
+    {   // the owner-computes form's pointer table, in device memory
+        rtr::OwnedTab tab{};
+        for (int r = 0; r < world; ++r) {
+            tab.meta[r] = static_cast<const uint32_t *>(q.meta_of.p[r]);
+            tab.ext0[r] = static_cast<const uint64_t *>(q.ext0_of.p[r]);
+            tab.dyn[r] = static_cast<const uint64_t *>(q.dyn_of.p[r]);
+            tab.depth[r] = static_cast<const uint32_t *>(q.depth.p[r]);
+            tab.ximg[r] = static_cast<const uint8_t *>(q.image.p[r]);
+        }
+        if (!q.tab) HIP_TRY(c, hipMalloc((void **)&q.tab, sizeof tab));
+        HIP_TRY(c, hipMemcpy(q.tab, &tab, sizeof tab, hipMemcpyHostToDevice));
     }
     q.rank = rank;
     q.world = world;
@@ -1479,6 +1504,58 @@ int rtr_p2p_render(rtr_ctx *c, const float P[16], int with_filter) {
     }
     if (!rc && with_filter) rc = filter_impl(c, parts, isl.chunk ? &isl : nullptr, (from_red && fused) ? q.red : nullptr);
     return rc;
+}
+
+// Owner-computes form of the sharded frame (rtr.h 5b): T1 -> barrier (+ every rank's occupancy bitmap) -> ONE fused tile
+// launch over the tiles tile_owner() gives to this rank, reading the other occupying ranks' entries out of their tile
+// stores -> barrier -> on the frame's owner only: collect the other ranks' tiles (+ pyramid) -> prefilter.  Six launches,
+// two barriers, no MIN / SUM exchange; the next frame's first barrier is what keeps a rank from overwriting tiles the
+// previous frame's owner is still collecting (that owner arrives at it only behind its collect and prefilter).
+int rtr_p2p_render_owned(rtr_ctx *c, const float P[16], int with_filter, int frame_owner) {
+    if (!c) return RTR_ERR_INVALID;
+    NEED(c, P != nullptr, "P is NULL");
+    NEED(c, c->p2p.open, "rtr_p2p_open has not been called");
+    auto &q = c->p2p;
+    NEED(c, frame_owner >= 0 && frame_owner < q.world, "frame_owner out of range");
+    NEED(c, use_tiles(c), "the owner-computes form needs the tile-binned mode (option mode = 1, <= 4096 tiles)");
+    NEED(c, !c->opt_overlap, "the owner-computes form does not combine with option overlap");
+    const bool mine = frame_owner == q.rank;
+    DevGuard g(c->device);
+    if (with_filter && mine)  // (fail before any rank enters a barrier the others would wait in)
+        if (int rc = ensure_pyramid(c)) return rc;
+    const bool fused = with_filter && c->prm.levels == 4;
+    if (int rc = bin_points(c, P, false, false)) return rc;
+    NEED(c, c->F().store.meta == q.meta_of.p[q.rank] && c->F().dyn == q.dyn_of.p[q.rank],
+         "the tile store changed since rtr_p2p_export (export and open again)");
+    const unsigned long long ticks = 100000ull * (unsigned long long)c->opt_p2p_timeout_ms;
+    // every rank's stream lengths and occupancy bitmap are final (and gathered into local memory)
+    rtr::launch_p2p_sync_gather(c->stream, q.flags, q.flags_of, q.rank, q.world, ++q.seq, q.status_dev, ticks, q.occ_of, q.occ_all);
+    rtr::TilePyr pyr{};
+    pyr.enable = (mine && fused) ? 1 : 0;
+    if (pyr.enable) {
+        pyr.L = c->lv;
+        pyr.n_eff_rows = (uint32_t)((c->H >> 4) << 4);
+        pyr.part_min = c->part_min;
+        pyr.part_max = c->part_max;
+    }
+    rtr::Sliced dsl{};
+    dsl.occ_all = q.occ_all;
+    dsl.peers = q.world;
+    dsl.rank = q.rank;
+    dsl.tab = q.tab;
+    {   // the frame's owner writes its tiles where the frame ends up; everybody else into the buffers the owner reads
+        Timed t(c, RTR_K_TILE);
+        rtr::launch_tile(c->stream, 4, c->W, c->H, c->F().store, c->prm.depth_window, c->depth, c->acc, mine ? c->img : q.ximg,
+                         c->opt_keep_accum, pyr.enable ? &pyr : nullptr, &dsl);
+    }
+    mark_consumed(c);
+    p2p_barrier(c);  // every tile of the frame is final on the rank that produced it; nobody reads a tile store any more
+    if (int rc = launch_check(c, "owned tile frame")) return rc;
+    if (!mine) return RTR_OK;
+    rtr::launch_p2p_collect(c->stream, c->W, c->H, q.tab, q.occ_all, q.world, q.rank, c->depth, c->img, pyr.enable ? &pyr : nullptr);
+    if (int rc = launch_check(c, "collect")) return rc;
+    if (with_filter) return filter_impl(c, pyr.enable ? rtr::tile_count(c->W, c->H) : 0);
+    return RTR_OK;
 }
 
 // ---- buffers -----------------------------------------------------------------------

@@ -60,12 +60,26 @@ struct PeerSet {
 // element is the MIN over the ranks whose bit for the tile is set in occ_all[r * 128 + (tile >> 5)] (every
 // rank's occupancy bitmap, gathered into local memory by the barrier launch); the completed depth goes to `out`,
 // a buffer no peer reads in that launch (NOT into the local depth buffer the peers are reading at that moment).
+struct OwnedTab;
 struct Sliced {
     PeerSet src;
     size_t chunk;
     const uint32_t *occ_all;
     int peers;
     uint32_t *out;
+    int rank;             // tile mode 4 (owner-computes sharded frames): this rank, ...
+    const OwnedTab *tab;  // ... and where every rank's tile store / frame buffers are mapped (device memory)
+};
+// Owner-computes form of the sharded frame (rtr_p2p_render_owned): every screen tile is produced by ONE of the ranks
+// that have points in it (tile_owner below), which reads the other occupying ranks' entries straight out of their tile
+// stores over xGMI -- no MIN / SUM exchange, no second pass.  The table lives in device memory (one pointer in the
+// kernel arguments instead of half a kilobyte).
+struct OwnedTab {
+    const uint32_t *meta[kMaxPeers];   // rank r's TileStore::meta (stream lengths per tile: ts_cnt4, extent directory)
+    const uint64_t *ext0[kMaxPeers];   // ... static extents
+    const uint64_t *dyn[kMaxPeers];    // ... dynamic extent pool
+    const uint32_t *depth[kMaxPeers];  // ... depth buffer (tiles it owns are final after the tile launch)
+    const uint8_t *ximg[kMaxPeers];    // ... image exchange copy (ditto)
 };
 struct TilePyr {  // F1 folded into T4 (whole-frame calls with the default 4 levels)
     FilterLevels L;
@@ -124,9 +138,13 @@ __host__ __device__ constexpr size_t ts_off_pool(int nst, int nt) { return ts_of
 __host__ __device__ constexpr size_t ts_off_dir(int nst, int nt) { return ts_off_pool(nst, nt) + 2; }
 __host__ __device__ constexpr size_t ts_off_perm(int nst, int nt) { return ts_off_dir(nst, nt) + (size_t)nst * kDirK * 2; }
 __host__ __device__ constexpr size_t ts_off_dbg(int nst, int nt) { return ts_off_perm(nst, nt) + ts_align4((size_t)nt); }
-__host__ __device__ constexpr size_t ts_meta_words(int nst, int nt) { return ts_off_dbg(nst, nt) + 128; }  // 64 u64 time stamps (RTR_EXPERIMENT builds)
+// cnt4[nt * 4]   the lengths of a tile's two (four) streams, indexed by TILE (the work list is in launch order): what a
+//                peer reads of this rank's store in the owner-computes sharded form
+__host__ __device__ constexpr size_t ts_off_cnt4(int nst, int nt) { return ts_align4(ts_off_dbg(nst, nt) + 128); }  // (dbg: 64 u64 time stamps, RTR_EXPERIMENT builds)
+__host__ __device__ constexpr size_t ts_meta_words(int nst, int nt) { return ts_off_cnt4(nst, nt) + (size_t)nt * 4; }
 static_assert(ts_off_items(150, 75) % 4 == 0 && ts_off_hdr(150, 75) % 4 == 0 && ts_off_ticket(150, 75) % 2 == 0 &&
-              ts_off_pool(150, 75) % 2 == 0 && ts_off_dir(150, 75) % 2 == 0 && ts_off_dbg(150, 75) % 2 == 0,
+              ts_off_pool(150, 75) % 2 == 0 && ts_off_dir(150, 75) % 2 == 0 && ts_off_dbg(150, 75) % 2 == 0 &&
+              ts_off_cnt4(150, 75) % 4 == 0,
               "tile store sub-arrays: 16-byte records / 8-byte words must be aligned (320x240: nst = 150)");
 __host__ __device__ inline uint32_t *ts_fill(const TileStore &S) { return S.meta; }
 __host__ __device__ inline uint32_t *ts_count(const TileStore &S) { return S.meta + ts_off_count(S.nst, S.ntiles); }
@@ -143,6 +161,7 @@ constexpr uint32_t kItemSkip = 0xFFFFFFFEu;
 __host__ __device__ inline unsigned long long *ts_dbg(const TileStore &S) {
     return reinterpret_cast<unsigned long long *>(S.meta + ts_off_dbg(S.nst, S.ntiles));
 }
+__host__ __device__ inline uint4 *ts_cnt4(const TileStore &S) { return reinterpret_cast<uint4 *>(S.meta + ts_off_cnt4(S.nst, S.ntiles)); }
 __host__ __device__ inline unsigned long long *ts_dir(const TileStore &S) {
     return reinterpret_cast<unsigned long long *>(S.meta + ts_off_dir(S.nst, S.ntiles));
 }
@@ -186,7 +205,8 @@ int reorder_morton(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, 
 int order_quality(hipStream_t s, const float *bounds, uint64_t n, float *ratio);
 // T4: per-tile LDS z-buffer over the tile store.  mode 0 = whole frame (min + accumulate + resolve
 // of every unsplit tile, min phase of split tiles), 3 = second phase of the split tiles of a whole
-// frame, 1 = min only, 2 = accumulate only.
+// frame, 1 = min only, 2 = accumulate only, 4 = owner-computes sharded frame: like 0, but only the tiles
+// tile_owner() gives to this rank, over the entries of EVERY occupying rank (depth_slices: occ_all, peers, rank, tab).
 // write_acc: bit 0 (mode 0) also write the accumulators; bit 1 (modes 1, 2) this launch is the only writer of
 // the frame buffer: store instead of folding into what memory holds; bit 2 (modes 1, 2; sharded frames)
 // tiles without entries are not written at all (the peers only read tiles of the occupancy bitmap).
@@ -210,6 +230,10 @@ void launch_p2p_sync(hipStream_t s, uint32_t *my_flags, const PeerSet &peer_flag
 void launch_p2p_sync_gather(hipStream_t s, uint32_t *my_flags, const PeerSet &peer_flags, int rank, int world, uint32_t seq,
                             uint32_t *status, unsigned long long timeout_ticks, const PeerSet &occ, uint32_t *occ_all);
 constexpr int kP2POccBytes = 512;  // occupancy bitmap: one bit per screen tile (<= 4096)
+// the frame owner's last step: every tile another rank produced is copied over xGMI into the local depth buffer /
+// image (tiles nobody has points in are cleared) and the prefilter's pyramid levels / min-max partials emitted
+void launch_p2p_collect(hipStream_t s, int W, int H, const OwnedTab *tab, const uint32_t *occ_all, int world, int rank,
+                        uint32_t *depth, uint8_t *img, const TilePyr *pyr);
 void launch_p2p_occupancy(hipStream_t s, const uint32_t *tile_cnt, int W, int H, uint32_t *occ);
 void launch_p2p_depth_reduce(hipStream_t s, const PeerSet &depth, const PeerSet &occ, uint32_t *red, size_t first,
                              size_t count, int world, int W, int H);

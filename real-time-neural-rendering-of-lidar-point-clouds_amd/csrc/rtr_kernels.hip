@@ -504,6 +504,7 @@ __device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split, 
     uint32_t *const hdr = ts_hdr(S), *const hctr = ts_hctr(S);
     const uint32_t *const perm = ts_perm(S);
     uint4 *const records = reinterpret_cast<uint4 *>(ts_items(S));
+    uint4 *const cnt4 = ts_cnt4(S);
     RTR_STAMP(S, 1);
     const StoreConsts sc = *ts_consts(S);
     typedef uint32_t __attribute__((address_space(1))) *gu32_t;  // (pointers out of memory: global, not flat)
@@ -561,6 +562,7 @@ __device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split, 
                     records[2 * (size_t)pos[k]] = make_uint4(c > heavy ? kItemSkip : (uint32_t)tile, f[k][0], f[k][1], NS > 2 ? f[k][NS > 2 ? 2 : 0] : 0u);
                     records[2 * (size_t)pos[k] + 1] = make_uint4(NS > 2 ? f[k][NS > 2 ? 3 : 0] : 0u, 0u, 0u, 0u);
                     if (c) atomicOr(&s_occ[tile >> 5], 1u << (tile & 31));
+                    if (occ) cnt4[tile] = make_uint4(f[k][0], f[k][1], NS > 2 ? f[k][NS > 2 ? 2 : 0] : 0u, NS > 2 ? f[k][NS > 2 ? 3 : 0] : 0u);  // (sharded frames)
                 }
                 sum += c;
                 mx = c > mx ? c : mx;
@@ -1341,11 +1343,28 @@ __device__ __forceinline__ void resolve3(uint32_t a0, uint32_t a1, uint32_t a2, 
     }
 }
 
+// Owner-computes sharded frames: which rank produces screen tile `tile`.  Every rank evaluates this on the same
+// gathered occupancy bitmaps, so all agree: one of the ranks that have points in the tile (the (tile mod n)-th of the
+// n occupying ranks: spatially compact point slices give a rank mostly its own tiles, a hash-ordered cloud deals
+// them round-robin), -1 when nobody has.  `mask`: the occupying ranks.
+constexpr int kOccWordsPerRank = 128;
+__device__ __forceinline__ int tile_owner(const uint32_t *occ_all, int world, int tile, uint32_t &mask) {
+    mask = 0u;
+    for (int r = 0; r < world; ++r) mask |= ((occ_all[r * kOccWordsPerRank + ((tile & 4095) >> 5)] >> (tile & 31)) & 1u) << r;
+    if (mask == 0u) return -1;
+    int pick = tile % __popc(mask);
+    uint32_t m = mask;
+    while (pick--) m &= m - 1u;
+    return __ffs((int)m) - 1;
+}
+constexpr int kSegCap4 = 512;  // segments of one tile over all occupying ranks (mode 4; in dynamic LDS)
+
 // T4: per-tile LDS z-buffer.  MODE 0 = whole frame (min + accumulate + resolve, writes
 // depth / image / optionally the accumulators; for a split tile only the min phase), MODE 3 = the
 // second phase of the split tiles of a whole frame; MODE 1 = min only (depth = min(depth,
 // tile min): the phase call before the multi-GPU MIN all-reduce); MODE 2 = accumulate
-// only against the depth buffer in memory (acc += tile sums).
+// only against the depth buffer in memory (acc += tile sums); MODE 4 = MODE 0 for the tiles tile_owner()
+// gives to this rank, over the entries of every occupying rank (read from the peers' tile stores).
 // 512 threads and eight entries in flight per thread.  Work item = tile | slice << 12 |
 // (slices - 1) << 22 from T1's epilogue: an unsplit tile (one slice) is owned by one workgroup,
 // the slices of a split tile are merged through the frame buffers.
@@ -1355,10 +1374,15 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
                                                         uint8_t *__restrict__ img, int write_acc, TilePyr pyr,
                                                         Sliced dsl) {
     extern __shared__ uint32_t s_mem[];
-    __shared__ unsigned long long s_seg_p[kMaxSegs];
-    __shared__ uint32_t s_seg_n[kMaxSegs], s_seg_pb[kMaxSegs];
+    __shared__ unsigned long long s_seg_p0[MODE == 4 ? 1 : kMaxSegs];
+    __shared__ uint32_t s_seg_n0[MODE == 4 ? 1 : kMaxSegs], s_seg_pb0[MODE == 4 ? 1 : kMaxSegs];
     __shared__ uint32_t s_nseg, s_flag;
+    __shared__ uint4 s_cnt4[MODE == 4 ? kMaxPeers : 1];
     const int tpix = 32 << g.tw_shift;  // pixels per tile
+    // (mode 4: the segment table covers every occupying rank and lives behind the tile buffers in dynamic LDS)
+    unsigned long long *const s_seg_p = MODE == 4 ? reinterpret_cast<unsigned long long *>(s_mem + 6 * tpix) : s_seg_p0;
+    uint32_t *const s_seg_n = MODE == 4 ? s_mem + 6 * tpix + 2 * kSegCap4 : s_seg_n0;
+    uint32_t *const s_seg_pb = MODE == 4 ? s_mem + 6 * tpix + 3 * kSegCap4 : s_seg_pb0;
     uint32_t *s_depth = s_mem;          // [tpix]
     uint32_t *s_acc = s_mem + tpix;     // [4 * tpix]
     uint8_t *s_rgb = reinterpret_cast<uint8_t *>(s_mem + 5 * tpix);  // [3 * tpix] (MODE 0, 3)
@@ -1382,6 +1406,7 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
         return;
     }
     const bool tile_wg = MODE != 3 && blockIdx.x < nt;
+    if (MODE == 4 && !tile_wg) return;
     const uint32_t split_step = MODE == 3 ? gridDim.x : gridDim.x - nt - ((MODE == 0 || MODE == 1) ? 1u : 0u);
     // (a tile workgroup's record always exists; the others first learn how many slice records there are)
     const uint32_t n_split = tile_wg ? 0u : ts_hdr(S)[kHdrSplitItems];
@@ -1397,7 +1422,17 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
 #endif
         RTR_TSTAMP(0);
         // one 32-byte record per work item: everything the workgroup needs to find its entries
-        const uint4 rec0 = records[2 * (size_t)item_i], rec1 = records[2 * (size_t)item_i + 1];
+        uint4 rec0, rec1;
+        uint32_t occ4 = 0u;  // mode 4: the ranks that have points in this tile
+        if (MODE == 4) {     // tile = workgroup; the lengths of this rank's own streams by tile
+            if (tile_owner(dsl.occ_all, dsl.peers, (int)item_i, occ4) != dsl.rank) break;  // (workgroup-uniform) another
+                                                                       // rank's tile, or nobody's: the collector clears it
+            const uint4 c4 = ts_cnt4(S)[item_i];
+            rec0 = make_uint4(item_i, c4.x, c4.y, c4.z);
+            rec1 = make_uint4(c4.w, 0u, 0u, 0u);
+        } else {
+            rec0 = records[2 * (size_t)item_i], rec1 = records[2 * (size_t)item_i + 1];
+        }
         const uint32_t item = rec0.x;
         if (item == kItemSkip) break;  // a split tile's own slot (workgroup-uniform)
         const uint32_t sub = (item >> 12) & 1023u, nsub = (item >> 22) + 1u;
@@ -1419,7 +1454,8 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
         const bool two = ns == 2;
         const uint32_t lim = T * (two ? kPer2 : kPer4);  // (<= 2048 < kS0: inside the static extent)
         static_assert(kTileThreads * kPer2 <= (int)kS0, "one batch must fit the static extent");
-        const bool one_batch = MODE == 0 && !split && rec0.y <= lim && rec0.z <= lim && (ns == 2 || (rec0.w <= lim && rec1.x <= lim));
+        const bool one_batch = (MODE == 0 || (MODE == 4 && occ4 == (1u << dsl.rank))) && !split && rec0.y <= lim && rec0.z <= lim &&
+                               (ns == 2 || (rec0.w <= lim && rec1.x <= lim));
         unsigned long long r[kTileBatch];
         auto load_batch = [&](auto per_tag) {  // (compile-time register -> stream mapping: everything stays in registers)
             constexpr int PER = decltype(per_tag)::value;
@@ -1449,9 +1485,43 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
         __syncthreads();  // the previous item's LDS is no longer read
         if (tid == 0) s_nseg = 0;
         if (!one_batch) __syncthreads();  // workgroup-uniform
+        if (MODE == 4 && !one_batch) {
+            // the same pieces in the store of EVERY occupying rank: their stream lengths first (one 16-byte read per
+            // rank, over xGMI for the peers), then static and dynamic extents through the mapped stores
+            if (tid < dsl.peers)
+                s_cnt4[tid] = ((occ4 >> tid) & 1u)
+                                  ? reinterpret_cast<const uint4 *>(dsl.tab->meta[tid] + ts_off_cnt4(S.nst, S.ntiles))[item_i]
+                                  : make_uint4(0u, 0u, 0u, 0u);
+            __syncthreads();
+            if (tid < kMaxSegs) {
+                const int s = tid / kDirK, k = tid % kDirK;
+                const int st = s < (2 << (g.tw_shift - 5)) ? stream_tile(g, tx, ty, s) : -1;
+                const unsigned long long e_lo = k == 0 ? 0ull : ((unsigned long long)kS0 << (k - 1)), e_hi = (unsigned long long)kS0 << k;
+                for (int r = 0; r < dsl.peers; ++r) {
+                    const uint4 c4 = s_cnt4[r];
+                    const unsigned long long cnt = s == 0 ? c4.x : (s == 1 ? c4.y : (s == 2 ? c4.z : c4.w));
+                    if (st < 0 || cnt <= e_lo) continue;
+                    const unsigned long long hi = cnt < e_hi ? cnt : e_hi;
+                    const unsigned long long *dir_r =
+                        reinterpret_cast<const unsigned long long *>(dsl.tab->meta[r] + ts_off_dir(S.nst, S.ntiles));
+                    const uint64_t *p = k == 0 ? dsl.tab->ext0[r] + ((size_t)st << kS0Shift)
+                                               : dsl.tab->dyn[r] + (dir_r[(size_t)st * kDirK + k] >> 24);
+                    const uint32_t q = atomicAdd(&s_nseg, 1u);
+                    if (q < (uint32_t)kSegCap4) {
+                        s_seg_p[q] = (unsigned long long)p;
+                        s_seg_n[q] = (uint32_t)(hi - e_lo);
+                        s_seg_pb[q] = stream_pb(s);
+                    } else {
+                        store_error(S, 4u);  // (more pieces than the table holds: entries would be dropped)
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid == 0 && s_nseg > (uint32_t)kSegCap4) s_nseg = kSegCap4;
+        }
         // the contiguous pieces of this item's entries: per stream the static extent and the dynamic ones,
         // clipped to the slice [sub, sub + 1) / nsub of the stream
-        if (!one_batch && tid < kMaxSegs) {
+        if (MODE != 4 && !one_batch && tid < kMaxSegs) {
             const int s = tid / kDirK, k = tid % kDirK;
             const int st = s < (2 << (g.tw_shift - 5)) ? stream_tile(g, tx, ty, s) : -1;
             const unsigned long long cnt = s == 0 ? rec0.y : (s == 1 ? rec0.z : (s == 2 ? rec0.w : rec1.x));
@@ -1476,7 +1546,7 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
                 occ_mask |= ((dsl.occ_all[r * 128 + ((tile & 4095) >> 5)] >> (tile & 31)) & 1u) << r;
         // depth tile
         for (int p = tid; p < tpix; p += T) {
-            if (MODE >= 2) {
+            if (MODE == 2 || MODE == 3) {
                 int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
                 if (x < W && y < H) {
                     const size_t gp = (size_t)y * W + x;
@@ -1511,8 +1581,8 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
         uint32_t n_local = 0;
         for (uint32_t q = 0; q < nseg; ++q) n_local += s_seg_n[q];
         if (one_batch) n_local = rec0.y + rec0.z + rec0.w + rec1.x;
-        const bool do_min = MODE == 1 || MODE == 0;
-        const bool do_acc = MODE >= 2 || (MODE == 0 && !split);
+        const bool do_min = MODE == 1 || MODE == 0 || MODE == 4;
+        const bool do_acc = MODE == 2 || MODE == 3 || ((MODE == 0 || MODE == 4) && !split);
         // Accumulators: the exact layout is two 64-bit words per pixel, (c0 | c1 << 32) and
         // (c2 | count << 32).  LDS atomics are what bounds this kernel (about one lane per clock
         // and CU), so items with <= 60000 entries first try ONE packed word per pixel and entry,
@@ -1667,7 +1737,7 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
             RTR_TSTAMP(9);
             __syncthreads();
             RTR_TSTAMP(10);
-            if (narrow && !(MODE == 0 && !split)) {  // (whole unsplit tiles check while they write out, below)
+            if (narrow && !((MODE == 0 || MODE == 4) && !split)) {  // (whole unsplit tiles check while they write out, below)
                 int over = 0;
                 for (int p = tid; p < tpix; p += T) over |= (s_acc64[p] >> 48) > 257ull;
                 if (__syncthreads_or(over)) {  // rare: some pixel blends more than 257 points
@@ -1745,7 +1815,7 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
                 int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
                 bool inb = x < W && y < H;
                 size_t gp = (size_t)y * W + x;
-                if (MODE == 0) {
+                if (MODE == 0 || MODE == 4) {
                     if (inb) depth[gp] = s_depth[p];
                 } else if (MODE == 1) {
                     if (inb) {
@@ -1763,7 +1833,7 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
                             reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(o.x + a0, o.y + a1, o.z + a2, o.w + c);
                         }
                     } else {
-                        if (MODE == 0 && inb && write_acc) reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(a0, a1, a2, c);
+                        if ((MODE == 0 || MODE == 4) && inb && write_acc) reinterpret_cast<uint4 *>(acc)[gp] = make_uint4(a0, a1, a2, c);
                         uint8_t q0, q1, q2;
                         resolve3(a0, a1, a2, c, q0, q1, q2);  // render.cu:147-162
                         s_rgb[3 * p + 0] = q0;
@@ -1775,10 +1845,10 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
         };
         if ((!split || (MODE == 3 && finish)) && !no_local) write_out();
         RTR_TSTAMP(5);
-        if ((MODE == 0 && !split) || (MODE == 3 && finish)) {
+        if (((MODE == 0 || MODE == 4) && !split) || (MODE == 3 && finish)) {
             // (the barrier the image rows need anyway also carries the verdict on the packed accumulators: an
             // unsplit tile of a whole frame only ever OVERWRITES memory, so writing it out twice is harmless)
-            if (MODE == 0 && narrow) {
+            if ((MODE == 0 || MODE == 4) && narrow) {
                 if (__syncthreads_or(over)) {  // rare: redo the tile with the wide layout
                     narrow = false;
                     for (int p = tid; p < 4 * tpix; p += T) s_acc[p] = 0;
@@ -2049,8 +2119,10 @@ void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, floa
     nosl.chunk = 0;
     nosl.peers = 0;
     nosl.out = nullptr;
+    nosl.rank = 0;
+    nosl.tab = nullptr;
     size_t tpix = (size_t)32 << g.tw_shift;
-    size_t lds = (mode == 1 ? tpix : 5 * tpix) * sizeof(uint32_t) + ((mode == 0 || mode == 3) ? 3 * tpix : 0);
+    size_t lds = (mode == 1 ? tpix : 5 * tpix) * sizeof(uint32_t) + ((mode == 0 || mode == 3 || mode == 4) ? 3 * tpix : 0);
     TilePyr none{};
     none.enable = 0;
     const dim3 grid(g.ntiles + kHeavyExtra), grid1(g.ntiles + kHeavyExtra + 1), block(kTileThreads);
@@ -2060,6 +2132,9 @@ void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, floa
     else if (mode == 3)  // only the split tiles' slices: all of these workgroups leave at once on ordinary frames
         hipLaunchKernelGGL(k_tile<3>, dim3(kSplitGrid), block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 1,
                            pyr ? *pyr : none, nosl);
+    else if (mode == 4)  // owner-computes sharded frame: one workgroup per tile, the segment table behind the tile buffers
+        hipLaunchKernelGGL(k_tile<4>, dim3(g.ntiles), block, lds + tpix * sizeof(uint32_t) + kSegCap4 * 16, s, S, g, W, H, window, depth,
+                           acc, img, write_acc & 1, pyr ? *pyr : none, *depth_slices);
     else if (mode == 1)
         hipLaunchKernelGGL(k_tile<1>, grid1, block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 6, none, nosl);
     else  // mode 2 always writes the accumulators; bit 1 of write_acc = overwrite; pyr: also emit the pyramid
@@ -2792,6 +2867,68 @@ __global__ __launch_bounds__(kBlock) void k_p2p_acc_resolve(PeerSet acc, PeerSet
     } else {
         for (int k = 0; k < 3 * cnt; ++k) o[k] = (uint8_t)out[k];
     }
+}
+
+// Owner-computes sharded frames, the frame owner's last step: one workgroup per screen tile.  A tile another rank
+// produced is copied from that rank's depth buffer / image exchange copy (row pieces of 128 / 96 bytes over xGMI); a
+// tile nobody has points in is cleared; either way the depth tile passes through LDS, so the prefilter's four
+// min-pool levels and the tile's min / max partial are emitted here (what k_tile does for the tiles this rank
+// produced itself, which this kernel leaves alone).
+__global__ __launch_bounds__(kBlock) void k_p2p_collect(TileGeom g, int W, int H, const OwnedTab *__restrict__ tab,
+                                                       const uint32_t *__restrict__ occ_all, int world, int rank,
+                                                       uint32_t *__restrict__ depth, uint8_t *__restrict__ img, TilePyr pyr) {
+    extern __shared__ uint32_t s_col[];  // [tpix] depth tile, then 4 * tpix words of pyramid scratch
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    uint32_t mask;
+    const int owner = tile_owner(occ_all, world, tile, mask);
+    if (owner == rank) return;  // (workgroup-uniform) produced here, pyramid included
+    const int tpix = 32 << g.tw_shift, tw = 1 << g.tw_shift;
+    const int tx0 = (tile % g.tiles_x) << g.tw_shift, ty0 = (tile / g.tiles_x) * kTileH;
+    const uint32_t *src_d = owner >= 0 ? tab->depth[owner] : nullptr;
+    const uint8_t *src_i = owner >= 0 ? tab->ximg[owner] : nullptr;
+    for (int p = tid; p < tpix; p += kBlock) {
+        const int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
+        uint32_t v = RTR_EMPTY;
+        if (x < W && y < H) {
+            const size_t gp = (size_t)y * W + x;
+            if (src_d) v = src_d[gp];
+            depth[gp] = v;
+        }
+        s_col[p] = v;
+    }
+    const int row_b = 3 * tw;  // image bytes per tile row
+    if ((tx0 + tw <= W) && ((W & 3) == 0)) {  // whole, 4-byte aligned row pieces: dwords
+        const int row_dw = row_b >> 2;
+        for (int q = tid; q < row_dw * kTileH; q += kBlock) {
+            const int rr = q / row_dw, dw = q - rr * row_dw, y = ty0 + rr;
+            if (y < H) {
+                const size_t off = ((size_t)y * W + tx0) * 3;
+                reinterpret_cast<uint32_t *>(img + off)[dw] = src_i ? reinterpret_cast<const uint32_t *>(src_i + off)[dw] : 0u;
+            }
+        }
+    } else {
+        for (int q = tid; q < 3 * tpix; q += kBlock) {
+            const int p = q / 3, ch = q - 3 * p;
+            const int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
+            if (x < W && y < H) {
+                const size_t off = ((size_t)y * W + x) * 3 + ch;
+                img[off] = src_i ? src_i[off] : (uint8_t)0;
+            }
+        }
+    }
+    if (pyr.enable) {
+        __syncthreads();
+        tile_pyramid(s_col, s_col + tpix, g, tx0, ty0, pyr.L, pyr.n_eff_rows, pyr.part_min, pyr.part_max, tile, tid, kBlock);
+    }
+}
+void launch_p2p_collect(hipStream_t s, int W, int H, const OwnedTab *tab, const uint32_t *occ_all, int world, int rank,
+                        uint32_t *depth, uint8_t *img, const TilePyr *pyr) {
+    const TileGeom g = tile_geom(W, H);
+    TilePyr none{};
+    none.enable = 0;
+    const size_t tpix = (size_t)32 << g.tw_shift;
+    hipLaunchKernelGGL(k_p2p_collect, dim3(g.ntiles), dim3(kBlock), 5 * tpix * sizeof(uint32_t), s, g, W, H, tab, occ_all, world,
+                       rank, depth, img, pyr ? *pyr : none);
 }
 
 void launch_p2p_sync(hipStream_t s, uint32_t *my_flags, const PeerSet &peer_flags, int rank, int world, uint32_t seq,

@@ -238,6 +238,11 @@ class Projector:
         P = self._P(P)
         self._chk(self._lib.rtr_p2p_render(self._ctx, _vp(P), 1 if with_filter else 0))
 
+    def p2p_render_owned(self, P, with_filter=False, frame_owner=0):
+        """Owner-computes sharded frame: afterwards only rank `frame_owner` holds the global frame."""
+        P = self._P(P)
+        self._chk(self._lib.rtr_p2p_render_owned(self._ctx, _vp(P), 1 if with_filter else 0, int(frame_owner)))
+
     def p2p_timeouts(self):
         n = C.c_uint32()
         self._chk(self._lib.rtr_p2p_status(self._ctx, C.byref(n)))

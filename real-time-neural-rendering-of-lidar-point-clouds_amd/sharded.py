@@ -24,6 +24,13 @@ Exchange forms:
                          undefined) and an agreement over all ranks: if any rank saw a timeout, all
                          drop to the collectives and that frame is rendered again with them
                          (`p2p_suspect_frames` names the frames since the previous clean check).
+  exchange="owned"       the owner-computes form (rtr_p2p_render_owned): no MIN / SUM exchange at all -- after ONE
+                         barrier every screen tile is produced by one of the ranks that have points in it, which
+                         reads the other occupying ranks' entries out of their tile stores over xGMI and runs the
+                         fused per-tile z-buffer once; a second barrier, then the FRAME'S OWNER (frame k -> rank
+                         k mod world unless `fixed_owner` is set) collects the tiles and runs the prefilter.  Only
+                         that rank ends with the whole frame (`last_owner`).  Verified like "p2p": the first frames
+                         are rendered with the collectives too and compared on every rank in turn.
 Colour forms of the collective exchange:
   "allreduce"      all-reduce SUM of the 16 B/px accumulators, every rank resolves all pixels;
   "reduce_scatter" reduce-scatter SUM (each rank receives 1/N of the pixels), slice-local
@@ -118,12 +125,16 @@ class HipLocal:
     def p2p_render(self, P, with_filter):
         self.p.p2p_render(P, with_filter)
 
+    def p2p_render_owned(self, P, with_filter, frame_owner):
+        self.p.p2p_render_owned(P, with_filter, frame_owner)
+
     def p2p_timeouts(self):
         return self.p.p2p_timeouts()
 
 
 class ShardedProjector:
-    """Runs the frame sequence over `group`; every rank ends with the full frame.
+    """Runs the frame sequence over `group`; every rank ends with the full frame (exchange "owned": only the
+    frame's owner, `last_owner`).
 
     `local` is any object with clear / min_depth_pass / accumulate_pass / resolve / filter
     and depth_tensor() / accum_tensor() (int32 torch tensors aliasing its frame buffers):
@@ -132,7 +143,9 @@ class ShardedProjector:
 
     def __init__(self, local, group=None, colour="allreduce", force_exchange=False, exchange="collective",
                  check_every=16):
-        assert colour in ("allreduce", "reduce_scatter") and exchange in ("collective", "p2p")
+        assert colour in ("allreduce", "reduce_scatter") and exchange in ("collective", "p2p", "owned")
+        self.fixed_owner = None     # exchange "owned": None = frame k belongs to rank k mod world
+        self.last_owner = None      # ... the rank that holds the frame rendered last
         assert check_every >= 1
         self.check_every = check_every  # p2p: frames between two looks at the barrier-timeout word (1 = every frame)
         self.frame_no = 0               # p2p frames rendered since the exchange was verified
@@ -194,19 +207,37 @@ class ShardedProjector:
                 self._drop_p2p(why if not ok else "setup failed on another rank")
                 return False
             self._p2p_res, self._p2p_verified = res, False
+        owned = self.exchange == "owned"
         if not self._p2p_verified:  # first frame: render with the collectives too and compare
             self._render_collective(P, False)
             ref_d, ref_i = lo.depth_tensor().clone(), lo.image_tensor().clone()
-            self._p2p_frame(P)
-            same = bool(torch.equal(lo.depth_tensor(), ref_d) and torch.equal(lo.image_tensor(), ref_i))
+            same = True
+            if owned:  # every rank owns the frame once and compares what it collected
+                for r in range(self.world):
+                    lo.p2p_render_owned(P, False, r)
+                    lo.p.synchronize()
+                    if r == self.rank:
+                        same = bool(torch.equal(lo.depth_tensor(), ref_d) and torch.equal(lo.image_tensor(), ref_i))
+                self.last_owner = self.world - 1
+            else:
+                self._p2p_frame(P)
+                same = bool(torch.equal(lo.depth_tensor(), ref_d) and torch.equal(lo.image_tensor(), ref_i))
             same = same and lo.p2p_timeouts() == 0
             if not self._all_agree(same):
                 self._drop_p2p("first frame differed from the collectives' (or a barrier timed out)")
                 return False
             self._p2p_verified = True
             self.frame_no = 0
+            if owned:  # (the caller's frame: with the owner it asked for)
+                self.last_owner = self.fixed_owner if self.fixed_owner is not None else 0
+                lo.p2p_render_owned(P, with_filter, self.last_owner)
+                return True
         else:
-            lo.p2p_render(P, with_filter)  # the whole sequence in one library call
+            if owned:
+                self.last_owner = self.fixed_owner if self.fixed_owner is not None else (self.frame_no + 1) % self.world
+                lo.p2p_render_owned(P, with_filter, self.last_owner)
+            else:
+                lo.p2p_render(P, with_filter)  # the whole sequence in one library call
             self.frame_no += 1
             if self.frame_no % self.check_every == 0:
                 # did a barrier give up on a stalled rank since the last check?  The word is host memory; what
@@ -228,8 +259,9 @@ class ShardedProjector:
         if not exchange and hasattr(lo, "render"):
             lo.render(P, with_filter)  # no exchange step: the fused whole-frame call
             return
-        if exchange and self.exchange == "p2p" and self._render_p2p(P, with_filter):
+        if exchange and self.exchange in ("p2p", "owned") and self._render_p2p(P, with_filter):
             return
+        self.last_owner = None  # (every rank holds the frame)
         self._render_collective(P, with_filter, exchange)
 
     def _render_collective(self, P, with_filter, exchange=True):

@@ -18,6 +18,7 @@ def main():
     W, H, n, frames = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     scene, mode = sys.argv[5], int(sys.argv[6])
     stall_rank = int(sys.argv[7]) if len(sys.argv) > 7 else -1  # this rank sleeps past the barrier timeout once
+    form = sys.argv[8] if len(sys.argv) > 8 else "p2p"          # "owned": rtr_p2p_render_owned, the frame owner rotates
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     pkg, orc = entry.load_package(), entry.load_oracle()
@@ -33,6 +34,39 @@ def main():
     sp = pkg.ShardedProjector(local, colour="reduce_scatter", exchange="p2p", check_every=1 if stall_rank >= 0 else 16)
     xyzw, rgba = orc.generate(scene, 11, 0, n, n)
     ok, notes = True, []
+    if form == "owned":
+        # owner-computes form: every tile is produced once, by a rank that has points in it (reading the other
+        # occupying ranks' entries out of their tile stores); only the frame's owner ends with the whole frame
+        local.p2p_setup(rank, world, None)
+        for k in range(frames):
+            P = pkg.orbit_projection(7 * k, W, H)
+            filt = (k % 2 == 1) and W % 16 == 0
+            owner = (k + 1) % world
+            proj.p2p_render_owned(P, filt, owner)
+            if rank == owner:
+                ref = orc.project(xyzw, rgba, P, W, H)
+                rd, ri, rt = ref["depth_bits"], ref["img"], None
+                if filt:
+                    rf = orc.filter(rd, ri)
+                    rd, ri, rt = rf["depth"].view(np.uint32), rf["img"], rf["tensor"]
+                same = np.array_equal(proj.download(pkg._lib.BUF_DEPTH), rd) and np.array_equal(proj.download(pkg._lib.BUF_IMAGE), ri)
+                if rt is not None:
+                    same = same and np.array_equal(proj.download(pkg._lib.BUF_TENSOR).reshape(5, H, W), rt)
+                if not same:
+                    ok = False
+                    notes.append("frame %d differs on its owner, rank %d" % (k, rank))
+            else:
+                proj.synchronize()
+        out = {"rank": rank, "ok": ok, "exchange": "owned", "p2p_note": None, "timeouts": proj.p2p_timeouts(),
+               "notes": notes, "suspect": None, "errors": proj.frame_stats()["errors"]}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, out)
+        if rank == 0:
+            print(json.dumps(gathered), flush=True)
+        dist.barrier()
+        proj.close()
+        dist.destroy_process_group()
+        return
     for k in range(frames):
         P = pkg.orbit_projection(7 * k, W, H)
         filt = (k % 2 == 1) and W % 16 == 0

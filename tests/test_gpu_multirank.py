@@ -45,4 +45,6 @@ def test_two_rank_bench_matches_oracle(extra):
     # --exchange auto: the collectives are timed first, then the hand-written peer-to-peer exchange,
     # which must have matched them before and after its timed frames on both ranks
     assert out["exchange"]["p2p_clean_on_all_ranks"] is True, out["exchange"]
-    assert out["exchange"]["used"] in ("p2p", "collective")
+    # ... and the owner-computes form (every tile produced once, the frame's owner rotating over the ranks)
+    assert out["exchange"]["owned_clean_on_all_ranks"] is True, out["exchange"]
+    assert out["exchange"]["used"] in ("owned", "p2p", "collective")

@@ -41,6 +41,25 @@ def test_p2p_exchange_matches_oracle(ranks, W, H, scene, mode):
         assert r["exchange"] == "p2p" and r["timeouts"] == 0, r
 
 
+@pytest.mark.parametrize("ranks,W,H,scene", [(2, 640, 480, "room_shell"), (3, 208, 120, "room_shell"),
+                                              (4, 1920, 1080, "room_shell"), (3, 100, 50, "room_shell"),
+                                              (3, 640, 480, "uniform_box")])
+def test_p2p_owner_computes_form_matches_oracle(ranks, W, H, scene):
+    """rtr_p2p_render_owned: every screen tile is produced by one of the ranks that have points in it, over the entries
+    of all of them (read out of the peers' tile stores through the hipIpc mappings); the frame's owner -- a different
+    rank every frame -- collects the tiles and runs the prefilter.  Its depth, image (and fp16 tensor) must equal the
+    oracle's.  uniform_box: every rank has points in every tile, so every tile merges the entries of all ranks."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "p2p_worker.py"), str(W), str(H),
+           "400000", "6", scene, "1", "-1", "owned"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("[")][-1])
+    assert len(out) == ranks
+    for r in out:
+        assert r["ok"] and r["timeouts"] == 0 and r["errors"] == 0, r
+
+
 def test_p2p_barrier_timeout_falls_back_to_the_collectives():
     """One rank stalls for a second while the barrier timeout is 150 ms: the ranks that waited flag the
     frame, every rank agrees at the end of that frame (check_every = 1), the exchange drops to the
@@ -92,6 +111,17 @@ def test_p2p_single_rank_and_misuse(pkg, orc):
             p.p2p_sum_resolve()
             assert np.array_equal(p.download(pkg._lib.BUF_DEPTH), ref["depth_bits"])
             assert np.array_equal(p.download(pkg._lib.BUF_IMAGE), ref["img"])
+        # the owner-computes form with one rank: every tile is this rank's, nothing to collect
+        for filt in (False, True):
+            p.p2p_render_owned(P, filt, 0)
+            rd, ri = ref["depth_bits"], ref["img"]
+            if filt:
+                rf = orc.filter(rd, ri)
+                rd, ri = rf["depth"].view(np.uint32), rf["img"]
+                assert np.array_equal(p.download(pkg._lib.BUF_TENSOR).reshape(5, H, W), rf["tensor"])
+            assert np.array_equal(p.download(pkg._lib.BUF_DEPTH), rd) and np.array_equal(p.download(pkg._lib.BUF_IMAGE), ri)
+        with pytest.raises(pkg.RtrError):
+            p.p2p_render_owned(P, False, 1)        # frame owner outside the world
         assert p.p2p_timeouts() == 0
         p.set_resolution(W + 16, H)                # closes the mapping
         with pytest.raises(pkg.RtrError):
