@@ -55,6 +55,7 @@ class HipLocal:
     def __init__(self, projector):
         self.p = projector
         self._views = None
+        self.p2p_res = None  # resolution the peers' buffers are mapped for (shared by every renderer on this context)
 
     def bind_stream(self):
         """Run the kernels on torch's current stream so RCCL collectives order with them."""
@@ -112,8 +113,10 @@ class HipLocal:
         if bad:
             raise RuntimeError("rtr_p2p_export failed: %s" % "; ".join(map(str, bad)))
         self.p.p2p_open(rank, world, blocks)
+        self.p2p_res = (self.p.W, self.p.H)
 
     def p2p_close(self):
+        self.p2p_res = None
         self.p.p2p_close()
 
     def p2p_min_depth(self):
@@ -152,7 +155,6 @@ class ShardedProjector:
         self.p2p_suspect_frames = None  # (first, last) frame_no that may be undefined after a barrier timeout
         self.exchange = exchange
         self.p2p_note = None        # why the p2p exchange was dropped, if it was
-        self._p2p_res = None        # resolution the peers' buffers are mapped for
         self._p2p_verified = False
         self.force_exchange = force_exchange  # run the collectives even in a 1-rank group (tests)
         self.local = local
@@ -197,7 +199,7 @@ class ShardedProjector:
         """-> False if the p2p form is (now) unavailable and the collectives must render the frame."""
         lo = self.local
         res = (lo.p.W, lo.p.H)
-        if self._p2p_res != res:  # (re)map the peers' buffers: collective, every rank gets here
+        if getattr(lo, "p2p_res", None) != res:  # (re)map the peers' buffers: collective, every rank gets here
             ok = True
             try:
                 lo.p2p_setup(self.rank, self.world, self.group)
@@ -206,7 +208,7 @@ class ShardedProjector:
             if not self._all_agree(ok):
                 self._drop_p2p(why if not ok else "setup failed on another rank")
                 return False
-            self._p2p_res, self._p2p_verified = res, False
+            self._p2p_verified = False
         owned = self.exchange == "owned"
         if not self._p2p_verified:  # first frame: render with the collectives too and compare
             self._render_collective(P, False)
