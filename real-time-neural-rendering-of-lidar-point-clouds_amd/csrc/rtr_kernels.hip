@@ -1364,7 +1364,10 @@ constexpr int kSegCap4 = 512;  // segments of one tile over all occupying ranks 
 // second phase of the split tiles of a whole frame; MODE 1 = min only (depth = min(depth,
 // tile min): the phase call before the multi-GPU MIN all-reduce); MODE 2 = accumulate
 // only against the depth buffer in memory (acc += tile sums); MODE 4 = MODE 0 for the tiles tile_owner()
-// gives to this rank, over the entries of every occupying rank (read from the peers' tile stores).
+// gives to this rank, over the entries of every occupying rank (read from the peers' tile stores); MODE 5 = the min
+// phase of the SLICES of a whole frame's split tiles (their minima meet in the depth buffer), MODE 3 their second
+// phase -- launches of their own, empty on ordinary frames, so that MODE 0 stays at 56 registers (four workgroups
+// per CU: two rounds over the 2040 tiles of a 1080p frame instead of three).
 // 512 threads and eight entries in flight per thread.  Work item = tile | slice << 12 |
 // (slices - 1) << 22 from T1's epilogue: an unsplit tile (one slice) is owned by one workgroup,
 // the slices of a split tile are merged through the frame buffers.
@@ -1405,12 +1408,13 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
         next_frame_order(S);
         return;
     }
-    const bool tile_wg = MODE != 3 && blockIdx.x < nt;
-    if (MODE == 4 && !tile_wg) return;
-    const uint32_t split_step = MODE == 3 ? gridDim.x : gridDim.x - nt - ((MODE == 0 || MODE == 1) ? 1u : 0u);
+    const bool tile_wg = MODE != 3 && MODE != 5 && blockIdx.x < nt;
+    if ((MODE == 4 || MODE == 0) && !tile_wg) return;  // (mode 0: the slices of split tiles have launches of their own -- with
+                                                        // them in this kernel it needs 80 registers and spills, without 56)
+    const uint32_t split_step = (MODE == 3 || MODE == 5) ? gridDim.x : gridDim.x - nt - ((MODE == 0 || MODE == 1) ? 1u : 0u);
     // (a tile workgroup's record always exists; the others first learn how many slice records there are)
     const uint32_t n_split = tile_wg ? 0u : ts_hdr(S)[kHdrSplitItems];
-    const uint32_t first = tile_wg ? blockIdx.x : nt + (MODE == 3 ? blockIdx.x : blockIdx.x - nt);
+    const uint32_t first = tile_wg ? blockIdx.x : nt + ((MODE == 3 || MODE == 5) ? blockIdx.x : blockIdx.x - nt);
 
     for (uint32_t item_i = first; tile_wg || item_i < nt + n_split; item_i += split_step) {
 #ifdef RTR_EXPERIMENT
@@ -1581,7 +1585,7 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
         uint32_t n_local = 0;
         for (uint32_t q = 0; q < nseg; ++q) n_local += s_seg_n[q];
         if (one_batch) n_local = rec0.y + rec0.z + rec0.w + rec1.x;
-        const bool do_min = MODE == 1 || MODE == 0 || MODE == 4;
+        const bool do_min = MODE == 1 || MODE == 0 || MODE == 4 || MODE == 5;
         const bool do_acc = MODE == 2 || MODE == 3 || ((MODE == 0 || MODE == 4) && !split);
         // Accumulators: the exact layout is two 64-bit words per pixel, (c0 | c1 << 32) and
         // (c2 | count << 32).  LDS atomics are what bounds this kernel (about one lane per clock
@@ -2126,12 +2130,15 @@ void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, floa
     TilePyr none{};
     none.enable = 0;
     const dim3 grid(g.ntiles + kHeavyExtra), grid1(g.ntiles + kHeavyExtra + 1), block(kTileThreads);
-    if (mode == 0)
-        hipLaunchKernelGGL(k_tile<0>, grid1, block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 1,
+    if (mode == 0)  // (the tiles + one workgroup for the next frame's launch order; split tiles' slices: modes 5 and 3)
+        hipLaunchKernelGGL(k_tile<0>, dim3(g.ntiles + 1), block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 1,
                            pyr ? *pyr : none, nosl);
     else if (mode == 3)  // only the split tiles' slices: all of these workgroups leave at once on ordinary frames
         hipLaunchKernelGGL(k_tile<3>, dim3(kSplitGrid), block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 1,
                            pyr ? *pyr : none, nosl);
+    else if (mode == 5)  // min phase of the split tiles' slices (whole frames)
+        hipLaunchKernelGGL(k_tile<5>, dim3(kSplitGrid), block, tpix * sizeof(uint32_t), s, S, g, W, H, window, depth, acc, img, 0, none,
+                           nosl);
     else if (mode == 4)  // owner-computes sharded frame: one workgroup per tile, the segment table behind the tile buffers
         hipLaunchKernelGGL(k_tile<4>, dim3(g.ntiles), block, lds + tpix * sizeof(uint32_t) + kSegCap4 * 16, s, S, g, W, H, window, depth,
                            acc, img, write_acc & 1, pyr ? *pyr : none, *depth_slices);
