@@ -120,6 +120,7 @@ struct rtr_ctx {
         uint8_t *img = nullptr, *dimg = nullptr;
         float *depth = nullptr;
         uint32_t *ddepth = nullptr;
+        void *img_map = nullptr, *depth_map = nullptr;  // the pinned buffers as the device addresses them
         hipEvent_t snap = nullptr, done = nullptr;  // snapshot taken (frame stream) / copies finished (copy stream)
         bool busy = false;
     } ho[RTR_ASYNC_SLOTS];
@@ -1226,10 +1227,12 @@ static int ensure_host_out(rtr_ctx *c) {
     const size_t npix = (size_t)c->W * c->H;
     for (auto &h : c->ho) {
         if (h.img) continue;
-        HIP_TRY(c, hipHostMalloc((void **)&h.img, npix * 3, hipHostMallocDefault));
-        HIP_TRY(c, hipHostMalloc((void **)&h.depth, npix * 4, hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc((void **)&h.img, (npix * 3 + 15) & ~(size_t)15, hipHostMallocMapped));
+        HIP_TRY(c, hipHostMalloc((void **)&h.depth, (npix * 4 + 15) & ~(size_t)15, hipHostMallocMapped));
+        HIP_TRY(c, hipHostGetDevicePointer(&h.img_map, h.img, 0));
+        HIP_TRY(c, hipHostGetDevicePointer(&h.depth_map, h.depth, 0));
         HIP_TRY(c, hipMalloc((void **)&h.dimg, (npix * 3 + 15) & ~(size_t)15));
-        HIP_TRY(c, hipMalloc((void **)&h.ddepth, npix * 4));
+        HIP_TRY(c, hipMalloc((void **)&h.ddepth, (npix * 4 + 15) & ~(size_t)15));
         HIP_TRY(c, hipEventCreateWithFlags(&h.snap, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&h.done, hipEventDisableTiming));
     }
@@ -1263,8 +1266,7 @@ int rtr_project_async(rtr_ctx *c, const float P[16], int slot, int with_filter) 
     HIP_TRY(c, hipMemcpyAsync(h.dimg, c->img, npix * 3, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipEventRecord(h.snap, c->stream));
     HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, h.snap, 0));
-    HIP_TRY(c, hipMemcpyAsync(h.depth, h.ddepth, npix * 4, hipMemcpyDeviceToHost, c->copy_stream));
-    HIP_TRY(c, hipMemcpyAsync(h.img, h.dimg, npix * 3, hipMemcpyDeviceToHost, c->copy_stream));
+    rtr::launch_copy_to_host(c->copy_stream, h.ddepth, h.depth_map, npix * 4, h.dimg, h.img_map, npix * 3);
     HIP_TRY(c, hipEventRecord(h.done, c->copy_stream));
     h.busy = true;
     return RTR_OK;

@@ -247,6 +247,8 @@ void launch_aos_to_soa(hipStream_t s, const uint8_t *xyz, size_t xyz_stride, con
                        uint64_t count, float *x, float *y, float *z, uint32_t *rgba);
 void launch_soa_to_aos(hipStream_t s, const float *x, const float *y, const float *z, const uint32_t *rgba,
                        uint64_t count, float *xyzw, uint8_t *rgba_out);
+// (a, b: device buffers padded to 16 bytes; ha, hb: device pointers of mapped pinned host buffers, padded likewise)
+void launch_copy_to_host(hipStream_t s, const void *a, void *ha, size_t bytes_a, const void *b, void *hb, size_t bytes_b);
 void launch_pad_nan(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, uint64_t n, uint64_t n_pad);
 
 }  // namespace rtr

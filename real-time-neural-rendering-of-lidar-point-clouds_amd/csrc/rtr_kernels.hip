@@ -3135,6 +3135,25 @@ __global__ void k_pad_nan(float *x, float *y, float *z, uint32_t *rgba, uint64_t
     }
 }
 
+// Device -> pinned host copy of a frame's outputs by a small grid of plain 16-byte stores over PCIe
+// (rtr_project_async).  It runs on the copy stream beside the next frame's kernels whatever the runtime's copy path
+// would have chosen: hipMemcpyAsync into the same buffers overlapped in some processes and serialised in others
+// (0.34 .. 0.62 ms per frame for one and the same loop).  The grid is deliberately tiny: measured on C3 + filter,
+// frames per second through the async pair peak at 8 workgroups (0.328 ms/frame; 4: 0.40, 16: 0.37, 64: 0.43,
+// 512: 0.48) -- fewer cannot keep the link busy, more take dispatch slots from the next frame's T1.
+constexpr int kCopyWgs = 8;
+typedef uint32_t u32x4_n __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(kBlock) void k_copy_to_host(const u32x4_n *__restrict__ a, u32x4_n *__restrict__ ha, size_t na,
+                                                        const u32x4_n *__restrict__ b, u32x4_n *__restrict__ hb, size_t nb) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < na; i += stride) __builtin_nontemporal_store(a[i], ha + i);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nb; i += stride) __builtin_nontemporal_store(b[i], hb + i);
+}
+void launch_copy_to_host(hipStream_t s, const void *a, void *ha, size_t bytes_a, const void *b, void *hb, size_t bytes_b) {
+    hipLaunchKernelGGL(k_copy_to_host, dim3(kCopyWgs), dim3(kBlock), 0, s, (const u32x4_n *)a, (u32x4_n *)ha, (bytes_a + 15) / 16,
+                       (const u32x4_n *)b, (u32x4_n *)hb, (bytes_b + 15) / 16);
+}
+
 void launch_pad_nan(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, uint64_t n, uint64_t n_pad) {
     if (n_pad > n) hipLaunchKernelGGL(k_pad_nan, dim3(1), dim3(64), 0, s, x, y, z, rgba, n, n_pad);
 }
