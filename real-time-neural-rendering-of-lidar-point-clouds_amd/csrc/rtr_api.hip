@@ -1172,15 +1172,13 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
             Timed t(c, RTR_K_TILE);
             rtr::launch_tile(c->stream, 0, c->W, c->H, c->F().store, c->prm.depth_window, c->depth, c->acc, c->img,
                              c->opt_keep_accum, pyr.enable ? &pyr : nullptr);
-            // tiles heavier than option "split_threshold" are split over several workgroups: the first launch takes
-            // the minimum over each slice (they meet in the depth buffer), the second accumulates the slices against
-            // that minimum and the last slice of each tile resolves it (no work item on ordinary frames: the
-            // workgroups of both launches leave at once)
-            if (c->opt_heavy > 0) {  // (split_threshold 0: nothing is ever split)
-                rtr::launch_tile(c->stream, 5, c->W, c->H, c->F().store, c->prm.depth_window, c->depth, c->acc, c->img, 0, nullptr);
+            // tiles heavier than option "split_threshold" are split over several workgroups: a second launch takes
+            // the minimum over each slice (they meet in the depth buffer), then -- behind a barrier over its 256
+            // workgroups -- accumulates the slices against that minimum, and the last slice of each tile resolves it
+            // (no work item on ordinary frames: its workgroups leave at once)
+            if (c->opt_heavy > 0)  // (split_threshold 0: nothing is ever split)
                 rtr::launch_tile(c->stream, 3, c->W, c->H, c->F().store, c->prm.depth_window, c->depth, c->acc, c->img,
                                  c->opt_keep_accum, pyr.enable ? &pyr : nullptr);
-            }
         }
         mark_consumed(c);
         if ((rc = launch_check(c, "tile frame"))) return rc;

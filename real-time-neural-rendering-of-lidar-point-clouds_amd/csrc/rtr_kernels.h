@@ -169,7 +169,10 @@ __host__ __device__ inline unsigned long long *ts_dir(const TileStore &S) {
 // overflowed -- entries were dropped), published by T1's epilogue from kHdrErrLive, which store_error() ORs into
 // while T1 runs; kHdrColourChunks: 256-point chunks with at least one in-frustum point (each loads 1 KiB of colours)
 enum { kHdrItems = 0, kHdrSplitItems = 1, kHdrEntries = 2, kHdrHeaviest = 3, kHdrSlice = 4, kHdrError = 5,
-       kHdrSplitTiles = 6, kHdrColourChunks = 7, kHdrConsts = 8, kHdrErrLive = 24 };
+       kHdrSplitTiles = 6, kHdrColourChunks = 7, kHdrConsts = 8, kHdrErrLive = 24,
+       // k_tile_split: slice records taken in its min phase, slices whose minima are in the depth buffer, records taken
+       // in its second phase
+       kHdrSplitQ1 = 25, kHdrSplitDone = 26, kHdrSplitQ2 = 27 };
 static_assert(kHdrConsts + sizeof(StoreConsts) / 4 <= kHdrErrLive, "StoreConsts overlaps the header words behind it");
 __host__ __device__ inline const StoreConsts *ts_consts(const TileStore &S) {
     return reinterpret_cast<const StoreConsts *>(ts_hdr(S) + kHdrConsts);

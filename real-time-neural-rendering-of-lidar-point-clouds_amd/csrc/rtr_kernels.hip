@@ -644,6 +644,7 @@ __device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split, 
         hdr[kHdrSlice] = slice;
         hdr[kHdrSplitTiles] = n_heavy;
         hdr[kHdrColourChunks] = colour_chunks;
+        hdr[kHdrSplitQ1] = 0u, hdr[kHdrSplitDone] = 0u, hdr[kHdrSplitQ2] = 0u;
         // the frame's tile-store error (entries were dropped: the frame is wrong) becomes the header's published
         // word and reaches the host through mapped memory -- rtr_synchronize and the calls that copy results to
         // the host report it; the live word starts the next frame at zero
@@ -1366,16 +1367,15 @@ constexpr int kSegCap4 = 512;  // segments of one tile over all occupying ranks 
 // only against the depth buffer in memory (acc += tile sums); MODE 4 = MODE 0 for the tiles tile_owner()
 // gives to this rank, over the entries of every occupying rank (read from the peers' tile stores); MODE 5 = the min
 // phase of the SLICES of a whole frame's split tiles (their minima meet in the depth buffer), MODE 3 their second
-// phase -- launches of their own, empty on ordinary frames, so that MODE 0 stays at 56 registers (four workgroups
-// per CU: two rounds over the 2040 tiles of a 1080p frame instead of three).
+// phase -- both in a launch of their own (k_tile_split), empty on ordinary frames, so that MODE 0 stays at 56
+// registers (four workgroups per CU: two rounds over the 2040 tiles of a 1080p frame instead of three).
 // 512 threads and eight entries in flight per thread.  Work item = tile | slice << 12 |
 // (slices - 1) << 22 from T1's epilogue: an unsplit tile (one slice) is owned by one workgroup,
 // the slices of a split tile are merged through the frame buffers.
 template <int MODE>
-__global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore S, TileGeom g, int W, int H, float window,
-                                                        uint32_t *__restrict__ depth, uint32_t *__restrict__ acc,
-                                                        uint8_t *__restrict__ img, int write_acc, TilePyr pyr,
-                                                        Sliced dsl) {
+__device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g, int W, int H, float window,
+                                          uint32_t *__restrict__ depth, uint32_t *__restrict__ acc,
+                                          uint8_t *__restrict__ img, int write_acc, const TilePyr &pyr, const Sliced &dsl) {
     extern __shared__ uint32_t s_mem[];
     __shared__ unsigned long long s_seg_p0[MODE == 4 ? 1 : kMaxSegs];
     __shared__ uint32_t s_seg_n0[MODE == 4 ? 1 : kMaxSegs], s_seg_pb0[MODE == 4 ? 1 : kMaxSegs];
@@ -1415,8 +1415,19 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
     // (a tile workgroup's record always exists; the others first learn how many slice records there are)
     const uint32_t n_split = tile_wg ? 0u : ts_hdr(S)[kHdrSplitItems];
     const uint32_t first = tile_wg ? blockIdx.x : nt + ((MODE == 3 || MODE == 5) ? blockIdx.x : blockIdx.x - nt);
+    // MODE 5 / 3 (k_tile_split): the slice records are taken from a queue instead of being dealt by workgroup index, so
+    // that a workgroup which waits between the two phases only ever waits for workgroups that are RUNNING (each holds a
+    // record it took) -- never for one that has not been scheduled yet (CU masks, another kernel on the chip)
+    constexpr bool kQueue = MODE == 3 || MODE == 5;
+    __shared__ uint32_t s_ticket;
+    auto take = [&]() -> uint32_t {
+        __syncthreads();
+        if (tid == 0) s_ticket = atomicAdd(ts_hdr(S) + (MODE == 5 ? kHdrSplitQ1 : kHdrSplitQ2), 1u);
+        __syncthreads();
+        return nt + s_ticket;
+    };
 
-    for (uint32_t item_i = first; tile_wg || item_i < nt + n_split; item_i += split_step) {
+    for (uint32_t item_i = kQueue ? take() : first; tile_wg || item_i < nt + n_split; item_i = kQueue ? take() : item_i + split_step) {
 #ifdef RTR_EXPERIMENT
         const bool stamp = MODE == 0 && (blockIdx.x == 5 || blockIdx.x == 700 || blockIdx.x == 1900);
         const int sb = blockIdx.x == 5 ? 8 : (blockIdx.x == 700 ? 24 : 40);
@@ -1440,7 +1451,9 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
         const uint32_t item = rec0.x;
         if (item == kItemSkip) break;  // a split tile's own slot (workgroup-uniform)
         const uint32_t sub = (item >> 12) & 1023u, nsub = (item >> 22) + 1u;
-        const bool split = nsub > 1u;
+        // (k_tile_split: every record of the split region goes through the frame buffers, also a split tile that ends up
+        // with ONE slice -- the slice size grows with the frame's split entries, T1's epilogue -- whose own record says skip)
+        const bool split = nsub > 1u || MODE == 3 || MODE == 5;
         const bool no_local = (MODE == 1 || MODE == 2) && sparse && (rec0.y + rec0.z + rec0.w + rec1.x) == 0u;
         if (MODE == 1 && no_local) break;  // (workgroup-uniform; an unsplit tile's workgroup has this one item)
         const int tile = (int)(item & 4095u);
@@ -1786,6 +1799,11 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
                     }
                 }
             }
+            if (MODE == 5) {  // this slice's minima are in the depth buffer
+                __threadfence();
+                __syncthreads();
+                if (tid == 0) atomicAdd(ts_hdr(S) + kHdrSplitDone, 1u);
+            }
             if (MODE == 3) {  // the last slice to arrive resolves the tile from the summed accumulators
                 __threadfence();
                 __syncthreads();
@@ -1892,6 +1910,47 @@ __global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore
         }
         if (tile_wg) break;
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore S, TileGeom g, int W, int H, float window,
+                                                        uint32_t *__restrict__ depth, uint32_t *__restrict__ acc,
+                                                        uint8_t *__restrict__ img, int write_acc, TilePyr pyr,
+                                                        Sliced dsl) {
+    tile_body<MODE>(S, g, W, H, window, depth, acc, img, write_acc, pyr, dsl);
+}
+
+// The slices of a whole frame's split tiles, both phases in ONE launch (ordinary frames have no split tile: every
+// workgroup leaves after one scalar load -- as two launches, modes 5 and 3, the empty pair cost ~9 us of a 64 us
+// C2 frame).  Between the phases a workgroup waits until EVERY slice's minima are in the depth buffer.  The slices
+// are taken from a queue, so whoever waits has seen the queue empty: each outstanding slice is held by a workgroup
+// that is running, and the wait ends whatever else shares the chip and however few of the 256 workgroups fit on
+// it at once (CU masks of option "tail_cus").  It is bounded all the same (tile-store error 8 instead of a hung
+// queue).  T1's epilogue zeroes the three words.
+__global__ __launch_bounds__(kTileThreads) void k_tile_split(TileStore S, TileGeom g, int W, int H, float window,
+                                                              uint32_t *__restrict__ depth, uint32_t *__restrict__ acc,
+                                                              uint8_t *__restrict__ img, int write_acc, TilePyr pyr,
+                                                              Sliced nosl /* (all zero; a kernel argument so that it stays out of scratch) */) {
+    const uint32_t n_split = (uint32_t)__builtin_amdgcn_readfirstlane((int)ts_hdr(S)[kHdrSplitItems]);
+    if (n_split == 0u) return;  // (grid-uniform)
+    TilePyr none{};
+    none.enable = 0;
+    tile_body<5>(S, g, W, H, window, depth, acc, img, 0, none, nosl);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t *const done = ts_hdr(S) + kHdrSplitDone;
+        int polls = 0;
+        while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_split) {
+            if (++polls > (1 << 22)) {
+                store_error(S, 8u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the second phase reads the depth buffer with plain loads
+    tile_body<3>(S, g, W, H, window, depth, acc, img, write_acc, pyr, nosl);
 }
 
 void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const TileStore &S,
@@ -2130,15 +2189,12 @@ void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, floa
     TilePyr none{};
     none.enable = 0;
     const dim3 grid(g.ntiles + kHeavyExtra), grid1(g.ntiles + kHeavyExtra + 1), block(kTileThreads);
-    if (mode == 0)  // (the tiles + one workgroup for the next frame's launch order; split tiles' slices: modes 5 and 3)
+    if (mode == 0)  // (the tiles + one workgroup for the next frame's launch order; split tiles' slices: k_tile_split)
         hipLaunchKernelGGL(k_tile<0>, dim3(g.ntiles + 1), block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 1,
                            pyr ? *pyr : none, nosl);
-    else if (mode == 3)  // only the split tiles' slices: all of these workgroups leave at once on ordinary frames
-        hipLaunchKernelGGL(k_tile<3>, dim3(kSplitGrid), block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 1,
-                           pyr ? *pyr : none, nosl);
-    else if (mode == 5)  // min phase of the split tiles' slices (whole frames)
-        hipLaunchKernelGGL(k_tile<5>, dim3(kSplitGrid), block, tpix * sizeof(uint32_t), s, S, g, W, H, window, depth, acc, img, 0, none,
-                           nosl);
+    else if (mode == 3)  // the split tiles' slices, min phase then second phase: every workgroup leaves at once on ordinary frames
+        hipLaunchKernelGGL(k_tile_split, dim3(kSplitGrid), block, 5 * tpix * sizeof(uint32_t) + 3 * tpix, s, S, g, W, H, window, depth,
+                           acc, img, write_acc & 1, pyr ? *pyr : none, nosl);
     else if (mode == 4)  // owner-computes sharded frame: one workgroup per tile, the segment table behind the tile buffers
         hipLaunchKernelGGL(k_tile<4>, dim3(g.ntiles), block, lds + tpix * sizeof(uint32_t) + kSegCap4 * 16, s, S, g, W, H, window, depth,
                            acc, img, write_acc & 1, pyr ? *pyr : none, *depth_slices);

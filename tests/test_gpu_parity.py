@@ -587,6 +587,34 @@ def test_ten_million_points_in_one_tile(pkg, orc, projector):
     assert int(ref["acc"][..., 3].sum()) > 0
 
 
+def test_split_tile_with_a_single_slice(pkg, orc, projector):
+    """Two hot tiles of very different weight: the slice size grows with the frame's split entries (at most 512 slice
+    records), so the lighter tile is above the split threshold and still gets ONE slice -- its record goes through
+    the split launch like any other (min into the depth buffer, sums into the accumulators, resolve)."""
+    W, H = 640, 480
+    rng = np.random.default_rng(78)
+    n_a, n_b = 600_000, 700
+    xa = np.stack([rng.uniform(-0.3, 0.3, n_a), rng.uniform(-0.3, 0.3, n_a), rng.uniform(39.0, 41.0, n_a)], axis=1)
+    xb = np.stack([rng.uniform(9.7, 10.3, n_b), rng.uniform(-0.3, 0.3, n_b), rng.uniform(39.0, 41.0, n_b)], axis=1)
+    xyz = np.concatenate([xa, xb]).astype(np.float32)
+    rgb = rng.integers(0, 256, size=(len(xyz), 3), dtype=np.uint8)
+    xyzw, rgba = cloud(xyz, rgb)
+    K = np.array([[512.0, 0, 336.0], [0, 512.0, 240.0], [0, 0, 1.0]])  # blobs in tiles (10, 7) and (14, 7)
+    P = orc.compose_projection(K, np.eye(4))
+    projector.set_option("split_threshold", 512)
+    projector.set_option("split_slice", 256)
+    projector.set_option("keep_accum", 1)
+    try:
+        _check_frame(pkg, orc, projector, xyzw, rgba, P, W, H)
+        st = projector.frame_stats()
+        # slice = ceil(600700 / 512) = 1174 > 700: tile B is split (700 > 512) into one slice
+        assert st["errors"] == 0 and st["split_tiles"] == 2 and st["slice"] >= 1174 and st["split_items"] == -(-n_a // st["slice"]) + 1, st
+    finally:
+        projector.set_option("keep_accum", 0)
+        projector.set_option("split_threshold", 32768)
+        projector.set_option("split_slice", 16384)
+
+
 @pytest.mark.parametrize("tail_cus,split", [(0, 32768), (8, 32768), (0, 64)])
 def test_overlap_option_keeps_every_frame(pkg, orc, projector, tail_cus, split):
     """Option "overlap": T1 of a whole-frame render runs on a second stream and fills the tile
