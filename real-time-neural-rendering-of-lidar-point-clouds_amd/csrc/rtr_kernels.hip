@@ -353,6 +353,7 @@ constexpr int kTileH = 32;
 #define RTR_TILE_WAVES 6
 #endif
 constexpr int kTileThreads = RTR_TILE_THREADS;
+constexpr int kTileThreadsCompact = 256;      // k_tile<0> (see tile_body)
 constexpr int kTileBatch = RTR_TILE_BATCH;    // entries in flight per thread in k_tile
 #ifndef RTR_T1_WAVES
 #define RTR_T1_WAVES 4  // the point kernel runs 4 waves per SIMD (1024 workgroups); capping it at 80 registers so that a
@@ -1386,11 +1387,17 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
     unsigned long long *const s_seg_p = MODE == 4 ? reinterpret_cast<unsigned long long *>(s_mem + 6 * tpix) : s_seg_p0;
     uint32_t *const s_seg_n = MODE == 4 ? s_mem + 6 * tpix + 2 * kSegCap4 : s_seg_n0;
     uint32_t *const s_seg_pb = MODE == 4 ? s_mem + 6 * tpix + 3 * kSegCap4 : s_seg_pb0;
+    // MODE 0 is compact: 256 threads and 3.75 LDS words per pixel (depth, the PACKED accumulators, the resolved
+    // colours), so that eight workgroups fit a CU -- the 2040 tiles of a 1080p frame are resident at once instead of
+    // taking two rounds of a 12 us dependent chain (record, entries, two LDS passes, write-out, pyramid).  A tile
+    // that needs the wide accumulators (some pixel blends more than 257 points) is redone in two halves of 16 rows,
+    // the wide layout of one half at a time in the same words.
+    constexpr bool kCompact = MODE == 0;
     uint32_t *s_depth = s_mem;          // [tpix]
-    uint32_t *s_acc = s_mem + tpix;     // [4 * tpix]
-    uint8_t *s_rgb = reinterpret_cast<uint8_t *>(s_mem + 5 * tpix);  // [3 * tpix] (MODE 0, 3)
+    uint32_t *s_acc = s_mem + tpix;     // [4 * tpix]; compact: [2 * tpix]
+    uint8_t *s_rgb = reinterpret_cast<uint8_t *>(s_mem + (kCompact ? 3 : 5) * tpix);  // [3 * tpix] (MODE 0, 3, 4)
     const int tid = threadIdx.x;
-    constexpr uint32_t T = kTileThreads;
+    constexpr uint32_t T = kCompact ? kTileThreadsCompact : kTileThreads;
     const int tw = 1 << g.tw_shift;
     // MODE 1 / 2, bit 1: this launch is the only writer of the frame buffer (no rtr_clear before it):
     // store the tile's depth / sums instead of folding them into what memory holds
@@ -1470,7 +1477,7 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
         const int ns = 2 << (g.tw_shift - 5);  // streams
         const bool two = ns == 2;
         const uint32_t lim = T * (two ? kPer2 : kPer4);  // (<= 2048 < kS0: inside the static extent)
-        static_assert(kTileThreads * kPer2 <= (int)kS0, "one batch must fit the static extent");
+        static_assert(T * kPer2 <= kS0, "one batch must fit the static extent");
         const bool one_batch = (MODE == 0 || (MODE == 4 && occ4 == (1u << dsl.rank))) && !split && rec0.y <= lim && rec0.z <= lim &&
                                (ns == 2 || (rec0.w <= lim && rec1.x <= lim));
         unsigned long long r[kTileBatch];
@@ -1609,8 +1616,21 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
         // entries.  If any pixel ends with count > 257 the whole item is redone with the wide layout.
         unsigned long long *s_acc64 = reinterpret_cast<unsigned long long *>(s_acc);
         bool narrow = do_acc && !no_local && (n_local <= 60000u);
-        if (do_acc && !no_local)
+        // (compact: a tile too heavy for the packed layout -- only with the split threshold raised -- goes straight to
+        // the two wide halves below)
+        const bool force_wide = kCompact && do_acc && !no_local && !narrow;
+        int cur_half = -1;  // compact, wide layout: the half of the tile (rows < 16 / >= 16) the accumulators hold
+        if (do_acc && !no_local && !force_wide)
             for (int p = tid; p < (narrow ? 2 : 4) * tpix; p += T) s_acc[p] = 0;
+        auto wide_slot = [&](uint32_t p, bool &mine) -> uint32_t {  // pixel -> its slot in the wide accumulators
+            if (!kCompact) {
+                mine = true;
+                return p;
+            }
+            const uint32_t h = p >= (uint32_t)(tpix >> 1) ? 1u : 0u;
+            mine = (int)h == cur_half;
+            return p - h * (uint32_t)(tpix >> 1);
+        };
         auto min_one = [&](unsigned long long r, uint32_t pb) {  // render.cu:81, behind an early-z read: an LDS read
             // costs a fraction of an LDS atomic, and only a few entries per pixel lower its minimum.  (Indexing
             // the __shared__ array itself keeps the accesses ds_ instructions: a volatile read through a
@@ -1628,8 +1648,12 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
                 if (packed) {
                     atomicAdd(s_acc64 + p, c0 | (c1 << 16) | (c2 << 32) | (1ull << 48));
                 } else {
-                    atomicAdd(s_acc64 + 2 * p + 0, c0 | (c1 << 32));
-                    atomicAdd(s_acc64 + 2 * p + 1, c2 | (1ull << 32));
+                    bool mine;
+                    const uint32_t pp = wide_slot(p, mine);
+                    if (mine) {
+                        atomicAdd(s_acc64 + 2 * pp + 0, c0 | (c1 << 32));
+                        atomicAdd(s_acc64 + 2 * pp + 1, c2 | (1ull << 32));
+                    }
                 }
             }
         };
@@ -1677,8 +1701,12 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
                 if (packed) {
                     atomicAdd(s_acc64 + p, v);
                 } else {
-                    atomicAdd(s_acc64 + 2 * p + 0, (v & 0xFFFFull) | (((v >> 16) & 0xFFFFull) << 32));
-                    atomicAdd(s_acc64 + 2 * p + 1, ((v >> 32) & 0xFFFFull) | ((v >> 48) << 32));
+                    bool mine;
+                    const uint32_t pp = wide_slot(p, mine);
+                    if (mine) {
+                        atomicAdd(s_acc64 + 2 * pp + 0, (v & 0xFFFFull) | (((v >> 16) & 0xFFFFull) << 32));
+                        atomicAdd(s_acc64 + 2 * pp + 1, ((v >> 32) & 0xFFFFull) | ((v >> 48) << 32));
+                    }
                 }
             };
             uint32_t pix[kTileBatch];
@@ -1750,7 +1778,7 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
             }
         };
         if (do_acc) {
-            accumulate(narrow);
+            if (!force_wide) accumulate(narrow);
             RTR_TSTAMP(9);
             __syncthreads();
             RTR_TSTAMP(10);
@@ -1775,7 +1803,8 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
                 a2 = (uint32_t)((pk >> 32) & 0xFFFFu);
                 c = (uint32_t)(pk >> 48);
             } else {
-                a0 = s_acc[4 * p], a1 = s_acc[4 * p + 1], a2 = s_acc[4 * p + 2], c = s_acc[4 * p + 3];
+                const int pp = (kCompact && cur_half > 0) ? p - (tpix >> 1) : p;
+                a0 = s_acc[4 * pp], a1 = s_acc[4 * pp + 1], a2 = s_acc[4 * pp + 2], c = s_acc[4 * pp + 3];
             }
         };
         bool finish = !split;  // this workgroup resolves / writes the image rows and emits the pyramid
@@ -1832,8 +1861,9 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
         }
         // write-out: rows of the tile are contiguous in memory
         int over = 0;  // packed accumulators only: some pixel blended more than 257 points
-        auto write_out = [&]() {
-            for (int p = tid; p < tpix; p += T) {
+        auto write_out = [&]() {  // (compact, wide layout: the pixels of the half the accumulators hold)
+            const int p_lo = (kCompact && cur_half > 0) ? (tpix >> 1) : 0, p_hi = (kCompact && cur_half == 0) ? (tpix >> 1) : tpix;
+            for (int p = p_lo + tid; p < p_hi; p += T) {
                 int x = tx0 + (p & (tw - 1)), y = ty0 + (p >> g.tw_shift);
                 bool inb = x < W && y < H;
                 size_t gp = (size_t)y * W + x;
@@ -1865,20 +1895,23 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
                 }
             }
         };
-        if ((!split || (MODE == 3 && finish)) && !no_local) write_out();
+        if ((!split || (MODE == 3 && finish)) && !no_local && !force_wide) write_out();
         RTR_TSTAMP(5);
         if (((MODE == 0 || MODE == 4) && !split) || (MODE == 3 && finish)) {
             // (the barrier the image rows need anyway also carries the verdict on the packed accumulators: an
             // unsplit tile of a whole frame only ever OVERWRITES memory, so writing it out twice is harmless)
-            if ((MODE == 0 || MODE == 4) && narrow) {
-                if (__syncthreads_or(over)) {  // rare: redo the tile with the wide layout
+            if ((MODE == 0 || MODE == 4) && (narrow || force_wide)) {
+                if (__syncthreads_or(over | (force_wide ? 1 : 0))) {  // rare: redo the tile with the wide layout
                     narrow = false;
-                    for (int p = tid; p < 4 * tpix; p += T) s_acc[p] = 0;
-                    __syncthreads();
-                    accumulate(false);
-                    __syncthreads();
-                    write_out();
-                    __syncthreads();
+                    for (int half = 0; half < (kCompact ? 2 : 1); ++half) {
+                        if (kCompact) cur_half = half;
+                        for (int p = tid; p < (kCompact ? 2 : 4) * tpix; p += T) s_acc[p] = 0;
+                        __syncthreads();
+                        accumulate(false);
+                        __syncthreads();
+                        write_out();
+                        __syncthreads();
+                    }
                 }
             } else {
                 __syncthreads();
@@ -1913,7 +1946,7 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kTileThreads, RTR_TILE_WAVES) void k_tile(TileStore S, TileGeom g, int W, int H, float window,
+__global__ __launch_bounds__(MODE == 0 ? kTileThreadsCompact : kTileThreads, MODE == 0 ? 8 : RTR_TILE_WAVES) void k_tile(TileStore S, TileGeom g, int W, int H, float window,
                                                         uint32_t *__restrict__ depth, uint32_t *__restrict__ acc,
                                                         uint8_t *__restrict__ img, int write_acc, TilePyr pyr,
                                                         Sliced dsl) {
@@ -2190,8 +2223,8 @@ void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, floa
     none.enable = 0;
     const dim3 grid(g.ntiles + kHeavyExtra), grid1(g.ntiles + kHeavyExtra + 1), block(kTileThreads);
     if (mode == 0)  // (the tiles + one workgroup for the next frame's launch order; split tiles' slices: k_tile_split)
-        hipLaunchKernelGGL(k_tile<0>, dim3(g.ntiles + 1), block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 1,
-                           pyr ? *pyr : none, nosl);
+        hipLaunchKernelGGL(k_tile<0>, dim3(g.ntiles + 1), dim3(kTileThreadsCompact), 3 * tpix * sizeof(uint32_t) + 3 * tpix, s, S, g, W, H,
+                           window, depth, acc, img, write_acc & 1, pyr ? *pyr : none, nosl);
     else if (mode == 3)  // the split tiles' slices, min phase then second phase: every workgroup leaves at once on ordinary frames
         hipLaunchKernelGGL(k_tile_split, dim3(kSplitGrid), block, 5 * tpix * sizeof(uint32_t) + 3 * tpix, s, S, g, W, H, window, depth,
                            acc, img, write_acc & 1, pyr ? *pyr : none, nosl);
