@@ -354,6 +354,13 @@ constexpr int kTileH = 32;
 #endif
 constexpr int kTileThreads = RTR_TILE_THREADS;
 constexpr int kTileThreadsCompact = 256;      // k_tile<0> (see tile_body)
+#ifndef RTR_TILE0_WAVES
+#define RTR_TILE0_WAVES 8
+#define RTR_TILE0_SWEEP 4
+#endif
+#ifndef RTR_TILE0_AHEAD
+#define RTR_TILE0_AHEAD 1
+#endif
 constexpr int kTileBatch = RTR_TILE_BATCH;    // entries in flight per thread in k_tile
 #ifndef RTR_T1_WAVES
 #define RTR_T1_WAVES 4  // the point kernel runs 4 waves per SIMD (1024 workgroups); capping it at 80 registers so that a
@@ -1631,32 +1638,6 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
             mine = (int)h == cur_half;
             return p - h * (uint32_t)(tpix >> 1);
         };
-        auto min_one = [&](unsigned long long r, uint32_t pb) {  // render.cu:81, behind an early-z read: an LDS read
-            // costs a fraction of an LDS atomic, and only a few entries per pixel lower its minimum.  (Indexing
-            // the __shared__ array itself keeps the accesses ds_ instructions: a volatile read through a
-            // derived pointer became a flat load with a full wait per entry.)
-            const uint32_t d = (uint32_t)(r >> 33), px = (uint32_t)(r >> 24) & 511u;
-            const uint32_t idx = pb + ((px >> 5) << g.tw_shift) + (px & 31u);
-            if (d < __hip_atomic_load(&s_mem[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMin(&s_mem[idx], d);
-        };
-        auto acc_one = [&](unsigned long long r, uint32_t pb, bool packed) {
-            const uint32_t d = (uint32_t)(r >> 33), px = (uint32_t)(r >> 24) & 511u;
-            const uint32_t p = pb + ((px >> 5) << g.tw_shift) + (px & 31u);
-            const float m = __uint_as_float(s_mem[p]);  // s_depth
-            if (!(__uint_as_float(d) > f_add(m, window))) {  // render.cu:106, then :125-128
-                const unsigned long long c0 = r & 0xFFull, c1 = (r >> 8) & 0xFFull, c2 = (r >> 16) & 0xFFull;
-                if (packed) {
-                    atomicAdd(s_acc64 + p, c0 | (c1 << 16) | (c2 << 32) | (1ull << 48));
-                } else {
-                    bool mine;
-                    const uint32_t pp = wide_slot(p, mine);
-                    if (mine) {
-                        atomicAdd(s_acc64 + 2 * pp + 0, c0 | (c1 << 32));
-                        atomicAdd(s_acc64 + 2 * pp + 1, c2 | (1ull << 32));
-                    }
-                }
-            }
-        };
         // A thread's registers of one segment hold CONSECUTIVE entries of the stream, i.e. consecutive points
         // of the cloud (T1 writes a lane's four points next to each other), which mostly fall on the same
         // pixel: they are merged in registers first, one LDS atomic per run -- LDS atomics are what bounds
@@ -1738,6 +1719,116 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
                 flush(run_p, run_v);
             }
         };
+        // Tiles with more entries than one batch: every piece of their streams, a batch at a time, with the NEXT batch
+        // requested before the current one is worked through.  As in the one-batch case a thread holds CONSECUTIVE
+        // entries of the stream -- consecutive points of the cloud, mostly on the same pixel -- and merges them in
+        // registers: one LDS atomic per run instead of one per entry (the two passes of a C3 tile are LDS-atomic bound:
+        // 8 resident tiles x 3.3 k entries per CU and pass).  The loads are unconditional from clamped indices (a
+        // load whose result merges with a constant is waited for on the spot) and masked when they are used.
+        constexpr int SB = kCompact ? RTR_TILE0_SWEEP : kTileBatch;  // entries per thread and buffer
+        constexpr bool kSweepAhead = kCompact ? (RTR_TILE0_AHEAD != 0) : true;
+        auto min_seq = [&](const unsigned long long *v, uint32_t pb) __attribute__((always_inline)) {
+            uint32_t pix[SB], cur[SB];
+#pragma unroll
+            for (int k = 0; k < SB; ++k) pix[k] = pixel_of(v[k], pb);
+#pragma unroll
+            for (int k = 0; k < SB; ++k) cur[k] = __hip_atomic_load(&s_mem[pix[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            uint32_t run_p = pix[0], run_d = (uint32_t)(v[0] >> 33), run_c = cur[0];
+#pragma unroll
+            for (int j = 1; j < SB; ++j) {
+                const uint32_t pj = pix[j], dj = (uint32_t)(v[j] >> 33);
+                if (pj != run_p) {
+                    if (run_d < run_c) atomicMin(&s_mem[run_p], run_d);
+                    run_p = pj;
+                    run_d = dj;
+                    run_c = cur[j];
+                } else {
+                    run_d = dj < run_d ? dj : run_d;
+                }
+            }
+            if (run_d < run_c) atomicMin(&s_mem[run_p], run_d);
+        };
+        auto acc_seq = [&](const unsigned long long *v, uint32_t pb, bool packed) __attribute__((always_inline)) {
+            auto flush = [&](uint32_t p, unsigned long long w) __attribute__((always_inline)) {  // w: c0 | c1 << 16 | c2 << 32 | count << 48, <= SB entries
+                if (w == 0ull) return;
+                if (packed) {
+                    atomicAdd(s_acc64 + p, w);
+                } else {
+                    bool mine;
+                    const uint32_t pp = wide_slot(p, mine);
+                    if (mine) {
+                        atomicAdd(s_acc64 + 2 * pp + 0, (w & 0xFFFFull) | (((w >> 16) & 0xFFFFull) << 32));
+                        atomicAdd(s_acc64 + 2 * pp + 1, ((w >> 32) & 0xFFFFull) | ((w >> 48) << 32));
+                    }
+                }
+            };
+            uint32_t pix[SB];
+            float m[SB];
+#pragma unroll
+            for (int k = 0; k < SB; ++k) pix[k] = pixel_of(v[k], pb);
+#pragma unroll
+            for (int k = 0; k < SB; ++k) m[k] = __uint_as_float(s_mem[pix[k]]);  // s_depth: final since the barrier
+            auto value_of = [&](unsigned long long e, float mk) -> unsigned long long {
+                if (__uint_as_float((uint32_t)(e >> 33)) > f_add(mk, window)) return 0ull;  // render.cu:106, then :125-128
+                return (e & 0xFFull) | (((e >> 8) & 0xFFull) << 16) | (((e >> 16) & 0xFFull) << 32) | (1ull << 48);
+            };
+            uint32_t run_p = pix[0];
+            unsigned long long run_v = value_of(v[0], m[0]);
+#pragma unroll
+            for (int j = 1; j < SB; ++j) {
+                const uint32_t pj = pix[j];
+                const unsigned long long vj = value_of(v[j], m[j]);
+                if (pj != run_p) {
+                    flush(run_p, run_v);
+                    run_p = pj;
+                    run_v = vj;
+                } else {
+                    run_v += vj;
+                }
+            }
+            flush(run_p, run_v);
+        };
+        auto sweep = [&](auto proc, unsigned long long pad) __attribute__((always_inline)) {
+            constexpr uint32_t STEP = SB * T;
+            for (uint32_t q = 0; q < nseg; ++q) {
+                // (workgroup-uniform values out of LDS: into scalar registers, so that every load is base + a 32-bit
+                // lane offset instead of holding a 64-bit address of its own)
+                const unsigned long long pv = s_seg_p[q];
+                const entries_t ent = (entries_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) |
+                                                  (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv));
+                const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seg_n[q]);  // (n >= 1)
+                const uint32_t pb = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seg_pb[q]);
+                unsigned long long ra[SB], rb[SB];
+                auto fetch = [&](unsigned long long *dst, uint32_t base) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int k = 0; k < SB; ++k) {
+                        const uint32_t i = base + (uint32_t)tid * SB + k;
+                        dst[k] = ent[i < n ? i : n - 1u];
+                    }
+                };
+                auto work = [&](const unsigned long long *src, uint32_t base) __attribute__((always_inline)) {
+                    unsigned long long v[SB];
+#pragma unroll
+                    for (int k = 0; k < SB; ++k) v[k] = (base + (uint32_t)tid * SB + k < n) ? src[k] : pad;
+                    proc(v, pb);
+                };
+                if (kSweepAhead) {
+                    fetch(ra, 0u);
+                    for (uint32_t base = 0; base < n; base += 2 * STEP) {  // (workgroup-uniform)
+                        fetch(rb, base + STEP);
+                        work(ra, base);
+                        if (base + STEP >= n) break;
+                        fetch(ra, base + 2 * STEP);
+                        work(rb, base + STEP);
+                    }
+                } else {
+                    for (uint32_t base = 0; base < n; base += STEP) {
+                        fetch(ra, base);
+                        work(ra, base);
+                    }
+                }
+            }
+        };
         if (one_batch) {
 #ifdef RTR_EXPERIMENT
             if (stamp && tid == 0 && r[0] != 1ull) ts_dbg(S)[sb + 11] = wall_clock64();  // first entry has arrived
@@ -1746,36 +1837,18 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
             if (two) min_runs(std::integral_constant<int, kPer2>{});
             else min_runs(std::integral_constant<int, kPer4>{});
         } else if (do_min) {
-            for (uint32_t q = 0; q < nseg; ++q) {
-                const entries_t ent = (entries_t)s_seg_p[q];
-                const uint32_t n = s_seg_n[q], pb = s_seg_pb[q];
-                for (uint32_t e = tid; e < n; e += kTileBatch * T) {
-#pragma unroll
-                    for (int k = 0; k < kTileBatch; ++k) r[k] = (e + k * T < n) ? ent[e + k * T] : kPadMin;
-#pragma unroll
-                    for (int k = 0; k < kTileBatch; ++k) min_one(r[k], pb);
-                }
-            }
+            sweep([&](const unsigned long long *v, uint32_t pb) __attribute__((always_inline)) { min_seq(v, pb); }, kPadMin);
         }
         RTR_TSTAMP(2);
         __syncthreads();
         RTR_TSTAMP(3);
-        auto accumulate = [&](bool packed) {
+        auto accumulate = [&](bool packed) __attribute__((always_inline)) {
             if (one_batch) {
                 if (two) acc_runs(std::integral_constant<int, kPer2>{}, packed);
                 else acc_runs(std::integral_constant<int, kPer4>{}, packed);
                 return;
             }
-            for (uint32_t q = 0; q < nseg; ++q) {
-                const entries_t ent = (entries_t)s_seg_p[q];
-                const uint32_t n = s_seg_n[q], pb = s_seg_pb[q];
-                for (uint32_t e = tid; e < n; e += kTileBatch * T) {  // (r is free here: not the one-batch case)
-#pragma unroll
-                    for (int k = 0; k < kTileBatch; ++k) r[k] = (e + k * T < n) ? ent[e + k * T] : kPadAcc;
-#pragma unroll
-                    for (int k = 0; k < kTileBatch; ++k) acc_one(r[k], pb, packed);
-                }
-            }
+            sweep([&](const unsigned long long *v, uint32_t pb) __attribute__((always_inline)) { acc_seq(v, pb, packed); }, kPadAcc);
         };
         if (do_acc) {
             if (!force_wide) accumulate(narrow);
@@ -1903,8 +1976,15 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
             if ((MODE == 0 || MODE == 4) && (narrow || force_wide)) {
                 if (__syncthreads_or(over | (force_wide ? 1 : 0))) {  // rare: redo the tile with the wide layout
                     narrow = false;
+#pragma unroll 1
                     for (int half = 0; half < (kCompact ? 2 : 1); ++half) {
-                        if (kCompact) cur_half = half;
+                        if (kCompact) {
+                            cur_half = half;
+                            // (this rare path must not shape the kernel: everything a one-batch tile derives from its
+                            // registers is invariant over the two halves, and hoisted out of this loop it spilled)
+#pragma unroll
+                            for (int k = 0; k < kTileBatch; ++k) asm volatile("" : "+v"(r[k]));
+                        }
                         for (int p = tid; p < (kCompact ? 2 : 4) * tpix; p += T) s_acc[p] = 0;
                         __syncthreads();
                         accumulate(false);
@@ -1946,7 +2026,7 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
 }
 
 template <int MODE>
-__global__ __launch_bounds__(MODE == 0 ? kTileThreadsCompact : kTileThreads, MODE == 0 ? 8 : RTR_TILE_WAVES) void k_tile(TileStore S, TileGeom g, int W, int H, float window,
+__global__ __launch_bounds__(MODE == 0 ? kTileThreadsCompact : kTileThreads, MODE == 0 ? RTR_TILE0_WAVES : RTR_TILE_WAVES) void k_tile(TileStore S, TileGeom g, int W, int H, float window,
                                                         uint32_t *__restrict__ depth, uint32_t *__restrict__ acc,
                                                         uint8_t *__restrict__ img, int write_acc, TilePyr pyr,
                                                         Sliced dsl) {
