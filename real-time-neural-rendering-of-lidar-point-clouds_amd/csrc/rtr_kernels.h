@@ -122,7 +122,8 @@ struct StoreConsts {  // rarely needed, rarely changing: lives in the store's he
 //   perm[nt]       tile -> record position: tiles that held more than twice the mean entry count in
 //                  the PREVIOUS frame first (written by an extra workgroup of the tile launch)
 //   hdr[32]        kHdr* below; hdr[kHdrConsts ..] = StoreConsts
-//   ticket[2]      (u64) low word: T1 workgroups that have finished; high word: 256-point chunks whose colours were loaded
+//   ticket[2]      (u64) low word: groups of T1 workgroups that have finished (see sub[] below); high word: 256-point
+//                  chunks whose colours were loaded
 //   pool_next[2]   (u64) entries of `dyn` handed out in this frame
 //   dir[nst * kDirK * 2]  (u64) extent base << 24 | frame stamp (valid iff stamp == seq)
 // (every sub-array starts on a 16-byte boundary: the work list is read and written as uint4 records, the
@@ -141,7 +142,13 @@ __host__ __device__ constexpr size_t ts_off_dbg(int nst, int nt) { return ts_off
 // cnt4[nt * 4]   the lengths of a tile's two (four) streams, indexed by TILE (the work list is in launch order): what a
 //                peer reads of this rank's store in the owner-computes sharded form
 __host__ __device__ constexpr size_t ts_off_cnt4(int nst, int nt) { return ts_align4(ts_off_dbg(nst, nt) + 128); }  // (dbg: 64 u64 time stamps, RTR_EXPERIMENT builds)
-__host__ __device__ constexpr size_t ts_meta_words(int nst, int nt) { return ts_off_cnt4(nst, nt) + (size_t)nt * 4; }
+// sub[kSubTickets * 32]  (u64 at the start of each 128-byte line) first level of T1's ticket: the workgroups of the
+//                point kernel finish within a few microseconds of each other, and 1024 returning adds on ONE word
+//                serialise at ~11 ns each (the last workgroup learnt that it was last ~10 us after it had finished);
+//                32 words on lines of their own take 32 adds each, and the last arrival of each adds to ticket[]
+constexpr int kSubTickets = 32;
+__host__ __device__ constexpr size_t ts_off_sub(int nst, int nt) { return ts_off_cnt4(nst, nt) + (size_t)nt * 4; }
+__host__ __device__ constexpr size_t ts_meta_words(int nst, int nt) { return ts_off_sub(nst, nt) + (size_t)kSubTickets * 32; }
 static_assert(ts_off_items(150, 75) % 4 == 0 && ts_off_hdr(150, 75) % 4 == 0 && ts_off_ticket(150, 75) % 2 == 0 &&
               ts_off_pool(150, 75) % 2 == 0 && ts_off_dir(150, 75) % 2 == 0 && ts_off_dbg(150, 75) % 2 == 0 &&
               ts_off_cnt4(150, 75) % 4 == 0,
@@ -160,6 +167,9 @@ __host__ __device__ inline uint32_t *ts_perm(const TileStore &S) { return S.meta
 constexpr uint32_t kItemSkip = 0xFFFFFFFEu;
 __host__ __device__ inline unsigned long long *ts_dbg(const TileStore &S) {
     return reinterpret_cast<unsigned long long *>(S.meta + ts_off_dbg(S.nst, S.ntiles));
+}
+__host__ __device__ inline unsigned long long *ts_sub(const TileStore &S, uint32_t g) {
+    return reinterpret_cast<unsigned long long *>(S.meta + ts_off_sub(S.nst, S.ntiles) + (size_t)g * 32);
 }
 __host__ __device__ inline uint4 *ts_cnt4(const TileStore &S) { return reinterpret_cast<uint4 *>(S.meta + ts_off_cnt4(S.nst, S.ntiles)); }
 __host__ __device__ inline unsigned long long *ts_dir(const TileStore &S) {

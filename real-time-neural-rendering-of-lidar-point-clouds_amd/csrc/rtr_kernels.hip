@@ -1210,10 +1210,21 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
         uint32_t mine = 0;
 #pragma unroll
         for (int w = 0; w < kBlock / 64; ++w) mine += s_colour[w];
-        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(ts_ticket(S)),
-                                                 1ull | ((unsigned long long)mine << 32));
-        s_last = (uint32_t)old == gridDim.x - 1u ? 1u : 0u;
-        s_colour_total = (uint32_t)(old >> 32) + mine;
+        // two levels (rtr_kernels.h, sub[]): workgroup b arrives at word b % 32; the last arrival there zeroes the word
+        // for the next frame and carries the group's colour count to the ticket proper
+        const uint32_t ng = gridDim.x < (uint32_t)kSubTickets ? gridDim.x : (uint32_t)kSubTickets, grp = blockIdx.x % ng;
+        const uint32_t gsize = (gridDim.x - grp + ng - 1u) / ng;
+        unsigned long long *const sub = ts_sub(S, grp);
+        const unsigned long long old = atomicAdd(sub, 1ull | ((unsigned long long)mine << 32));
+        uint32_t last = 0u;
+        if ((uint32_t)old == gsize - 1u) {
+            __hip_atomic_store(sub, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long group_colour = (old >> 32) + mine;
+            const unsigned long long old2 = atomicAdd(reinterpret_cast<unsigned long long *>(ts_ticket(S)), 1ull | (group_colour << 32));
+            last = (uint32_t)old2 == ng - 1u ? 1u : 0u;
+            s_colour_total = (uint32_t)(old2 >> 32) + (uint32_t)group_colour;
+        }
+        s_last = last;
     }
     __syncthreads();
 #ifdef RTR_EXPERIMENT
