@@ -306,6 +306,31 @@ def test_packed_accumulator_boundary(pkg, orc, projector, mode, n_same):
     assert ref["acc"][24, 32, 3] >= n_same and tuple(ref["img"][24, 32]) != (0, 0, 0)
 
 
+@pytest.mark.parametrize("n_hot,threshold", [(300, 32768), (70_000, 0)])
+def test_wide_accumulators_in_both_halves_of_a_tile(pkg, orc, projector, n_hot, threshold):
+    """The whole-frame tile kernel keeps only the packed accumulators in LDS; a tile that needs the wide ones is redone
+    in two halves of 16 rows.  Pixels that blend more than 257 points in BOTH halves of one 32x32 tile, ordinary pixels
+    around them; with the split threshold off and more than 60000 entries the tile goes straight to the wide halves."""
+    W, H = 64, 48
+    rng = np.random.default_rng(n_hot)
+    K = np.array([[100.0, 0, 32.0], [0, 100.0, 24.0], [0, 0, 1.0]])
+    P = orc.compose_projection(K, np.eye(4))
+    def at(u, v, k):  # k points that round to pixel (u, v), depths inside the blending window of the nearest
+        z = rng.uniform(2.0, 2.0004, k)
+        return np.stack([(u - 32.0) * z / 100.0, (v - 24.0) * z / 100.0, z], axis=1)
+    spread = np.stack([rng.uniform(-0.6, 0.6, 3000), rng.uniform(-0.45, 0.45, 3000), rng.uniform(2.05, 2.3, 3000)], axis=1)  # (never in front of the hot pixels)
+    xyz = np.concatenate([at(40, 5, n_hot), at(45, 20, n_hot // 2 + 300), spread]).astype(np.float32)  # tile (1, 0): rows 5 and 20
+    rgb = np.concatenate([np.full((len(xyz) - 3000, 3), 255, np.uint8), rng.integers(0, 256, size=(3000, 3), dtype=np.uint8)])
+    xyzw, rgba = cloud(xyz, rgb)
+    projector.set_option("split_threshold", threshold)
+    try:
+        ref = _check_frame(pkg, orc, projector, xyzw, rgba, P, W, H)
+        assert projector.frame_stats()["split_tiles"] == 0
+    finally:
+        projector.set_option("split_threshold", 32768)
+    assert ref["acc"][5, 40, 3] > 257 and ref["acc"][20, 45, 3] > 257
+
+
 def test_frames_larger_than_4k_fall_back(pkg, orc, projector):
     """More than 4096 screen tiles (beyond 3840x2160): the library silently uses the atomic
     form; the frame is still exact."""
