@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
                 }
             }
         };
-        select_base(select_base, std::integral_constant<int, 0>{});
+        if (!RTR_XP(16)) select_base(select_base, std::integral_constant<int, 0>{});  // (xp 16: the claims are issued, never waited for)
         const uint32_t cs[4] = {col.x, col.y, col.z, col.w};
         uint32_t v[4];
         bool dyn = false;
@@ -1010,6 +1010,10 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
             dyn = dyn || (in[k] && v[k] >= kS0);
         }
         if (RTR_XP(4)) return;
+        if (RTR_XP(512)) {  // claims waited for, nothing stored
+            if ((v[0] ^ v[1] ^ v[2] ^ v[3]) == 0x7FFFFFFFu) fill[0] = 0u;
+            return;
+        }
         if (__ballot(dyn) == 0ull) {  // the usual case: every position lies in its tile's static extent
             const bool quad = in[0] && in[1] && in[2] && in[3] && grp[0] < kMaxGroups && grp[0] == grp[1] &&
                               grp[0] == grp[2] && grp[0] == grp[3];  // same group: same tile, ranks r, r+1, r+2, r+3
@@ -1049,6 +1053,9 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
     if (!CULL && PACKED) {
         // the same pipeline as below on the packed form, one stage deeper: header of chunk q + 2, planes of chunk
         // q + 1 (<= 12 dwords per lane, usually 6-9) and the arithmetic of chunk q are in flight together
+        // (Two chunks of planes in flight per wave -- buffers A / B, loop unrolled by two -- lift the loads alone from 95
+        // to 87 us (one chunk per wave and memory round trip is 4096 x 1.3 KB / ~1 us = 5.4 TB/s), but the whole kernel
+        // gets 5 us slower: 14 more spilled scalar registers and their v_readlane traffic.  Measured in rounds 2 and 3.)
         // No branch depends on whether the wave still has a chunk: past its last one it re-reads the cloud's
         // last chunk with every lane masked (at most two wasted iterations per wave), so the compiler sees
         // straight-line code and waits for the chunk's three loads exactly once, where they are decoded.

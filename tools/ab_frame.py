@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as entry
 pkg = entry.load_package()
-W, H, n = 1920, 1080, 100_000_000
+W, H, n = int(os.environ.get("AB_W", 1920)), int(os.environ.get("AB_H", 1080)), int(os.environ.get("AB_N", 100_000_000))
 scene = os.environ.get("AB_SCENE", "room_shell")
 poses = [np.ascontiguousarray(pkg.orbit_projection(k, W, H), dtype=np.float32).reshape(16) for k in range(120)]
 libs = []
