@@ -18,6 +18,8 @@
 #include "../../include/rtr.h"
 #include "rtr_kernels.h"
 
+constexpr int kSplitCooldown = 8;  // whole frames keep launching k_tile_split this long after the last report of a tile above the threshold
+
 struct rtr_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -76,6 +78,13 @@ struct rtr_ctx {
     int opt_debug_dyn_cap = -1;      // test aid: cap the dynamic extent pool at this many entries (-1: off)
     uint32_t *err_host = nullptr;    // mapped host word: tile-store error bits of frames since it was last read
     uint32_t *err_dev = nullptr;     // ... as the device sees it (StoreConsts::err_host)
+    // whole frames launch k_tile_split (an empty launch costs ~5 us) only while tiles above the split threshold have
+    // been seen: T1's epilogue stores their number here (mapped host word, read without a sync -- it describes the
+    // last frame whose T1 has COMPLETED, the host may be frames ahead), and the launch stays on for kSplitCooldown
+    // frames after the last such report, after an upload, a new resolution or new split options.  A frame that
+    // turns out to need it while it is off is still exact (bin_epilogue, `no_split`).
+    uint32_t *split_host = nullptr, *split_dev = nullptr;
+    int split_cooldown = 0;
     int opt_xp = 0;                  // RTR_EXPERIMENT builds only (tools/kbench.py)
     int opt_phases = 0;         // T1: phase groups of the grid stride (option "phases", see k_project_bin); 0 = automatic
     int opt_probe = 0;          // rtr_stream_probe variant (experiments)
@@ -220,6 +229,7 @@ void free_host_out(rtr_ctx *c) {
 
 void free_frame(rtr_ctx *c) {
     c->list_valid = false;
+    c->split_cooldown = kSplitCooldown;  // (a new resolution: nothing is known about its frames)
     free_host_out(c);
     p2p_release(c);
     dfree(c->depth); dfree(c->acc); dfree(c->img); dfree(c->mask); dfree(c->part_min); dfree(c->part_max); dfree(c->tensor);
@@ -242,6 +252,7 @@ void free_lists(rtr_ctx *c) {  // the dynamic extent pools (sized by the point c
         f.pool_n = 0;
     }
     c->list_valid = false;
+    c->split_cooldown = kSplitCooldown;  // (a new cloud)
 }
 
 void free_pack(rtr_ctx *c) {
@@ -288,6 +299,7 @@ int ensure_tiles(rtr_ctx *c, hipStream_t s) {
     want.dyn = f.dyn; want.dyn_cap = f.dyn_cap;
     if (c->opt_debug_dyn_cap >= 0 && (uint64_t)c->opt_debug_dyn_cap < want.dyn_cap) want.dyn_cap = (uint64_t)c->opt_debug_dyn_cap;
     want.err_host = c->err_dev;
+    want.split_host = c->split_dev;
     want.heavy = c->opt_heavy > 0 ? (uint32_t)c->opt_heavy : 0xFFFFFFFFu;
     want.slice = (uint32_t)c->opt_slice;
     if (memcmp(&want, &f.consts, sizeof want) != 0) {
@@ -326,6 +338,7 @@ int alloc_cloud(rtr_ctx *c, uint64_t n) {
     }
     c->n = n;
     c->list_valid = false;
+    c->split_cooldown = kSplitCooldown;  // (a new cloud: nothing is known about its frames)
     return RTR_OK;
 }
 
@@ -495,10 +508,19 @@ int rtr_create(rtr_ctx **out, int device) {
         e = hipHostGetDevicePointer(&d, c->err_host, 0);
         c->err_dev = static_cast<uint32_t *>(d);
     }
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->split_host, sizeof(uint32_t), hipHostMallocMapped);
+    if (e == hipSuccess) {
+        *c->split_host = 0u;
+        void *d = nullptr;
+        e = hipHostGetDevicePointer(&d, c->split_host, 0);
+        c->split_dev = static_cast<uint32_t *>(d);
+        c->split_cooldown = kSplitCooldown;
+    }
     if (e != hipSuccess) {
         int rc = fail(nullptr, RTR_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
         if (c->minmax) (void)hipFree(c->minmax);
         if (c->err_host) (void)hipHostFree(c->err_host);
+        if (c->split_host) (void)hipHostFree(c->split_host);
         (void)hipStreamDestroy(c->own_stream);
         delete c;
         return rc;
@@ -518,6 +540,7 @@ int rtr_destroy(rtr_ctx *c) {
     free_cloud(c);
     dfree(c->minmax);
     if (c->p2p.status_host) (void)hipHostFree(c->p2p.status_host);
+    if (c->split_host) (void)hipHostFree(c->split_host);
     if (c->err_host) (void)hipHostFree(c->err_host);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -617,6 +640,7 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
     if (!strcmp(key, "split_threshold")) {  // 0: never split
         NEED(c, value >= 0, "split_threshold must be >= 0");
         c->opt_heavy = value;
+        c->split_cooldown = kSplitCooldown;
         c->list_valid = false;
         return RTR_OK;
     }
@@ -654,6 +678,7 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
     if (!strcmp(key, "split_slice")) {
         NEED(c, value >= 1, "split_slice must be >= 1");
         c->opt_slice = value;
+        c->split_cooldown = kSplitCooldown;
         c->list_valid = false;
         return RTR_OK;
     }
@@ -1004,7 +1029,7 @@ static bool use_tiles(const rtr_ctx *c) {
 // the tile launches are the frame buffers' only writers: `clear_split`).
 // With `overlapped` T1 goes to the front stream and fills the set the tail is NOT reading, so it
 // runs beside T4 / the prefilter of the previous frame.
-static int bin_points(rtr_ctx *c, const float P[16], bool overlapped, bool clear_split) {
+static int bin_points(rtr_ctx *c, const float P[16], bool overlapped, bool clear_split, bool no_split = false) {
     c->list_valid = false;
     c->p2p.occ_current = false;
     c->p2p.occ_from_scan = false;
@@ -1026,7 +1051,7 @@ static int bin_points(rtr_ctx *c, const float P[16], bool overlapped, bool clear
     {
         Timed tm(c, RTR_K_MIN_DEPTH, s1, true);
         rtr::launch_project_bin(s1, cloud_of(c), make_proj(P), c->W, c->H, t, c->opt_cull ? c->bounds : nullptr,
-                                clear_split ? 1 : 0, c->opt_phases, c->opt_xp, tm.a, tm.b);
+                                (clear_split ? 1 : 0) | (no_split ? 2 : 0), c->opt_phases, c->opt_xp, tm.a, tm.b);
         c->p2p.occ_from_scan = c->p2p.open;
     }
     if (overlapped) {
@@ -1156,8 +1181,14 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
         // (T1 beside the previous frame's tail must not touch the frame buffers: the split tiles' pixels are then
         // reset by a launch of their own on the tail's stream)
         const bool overlapped = c->opt_overlap && c->front;
-        if ((rc = bin_points(c, P, overlapped, !overlapped))) return rc;
-        if (overlapped && c->opt_heavy > 0) rtr::launch_reset_split(c->stream, c->W, c->H, c->F().store, c->depth, c->acc);
+        bool split_launch = c->opt_heavy > 0;  // (split_threshold 0: nothing is ever split)
+        if (split_launch) {
+            if (__atomic_load_n(c->split_host, __ATOMIC_RELAXED) != 0u) c->split_cooldown = kSplitCooldown;
+            split_launch = c->split_cooldown > 0;
+            if (c->split_cooldown > 0) --c->split_cooldown;
+        }
+        if ((rc = bin_points(c, P, overlapped, !overlapped, !split_launch))) return rc;
+        if (overlapped && split_launch) rtr::launch_reset_split(c->stream, c->W, c->H, c->F().store, c->depth, c->acc);
         // with the default four levels the tile kernel also emits the prefilter's pyramid and
         // min / max partials (F1) while the finished depth tile is still in LDS
         rtr::TilePyr pyr{};
@@ -1176,7 +1207,7 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
             // the minimum over each slice (they meet in the depth buffer), then -- behind a barrier over its 256
             // workgroups -- accumulates the slices against that minimum, and the last slice of each tile resolves it
             // (no work item on ordinary frames: its workgroups leave at once)
-            if (c->opt_heavy > 0)  // (split_threshold 0: nothing is ever split)
+            if (split_launch)  // (skipped while no frame has had a tile above the threshold: see rtr_ctx::split_host)
                 rtr::launch_tile(c->stream, 3, c->W, c->H, c->F().store, c->prm.depth_window, c->depth, c->acc, c->img,
                                  c->opt_keep_accum, pyr.enable ? &pyr : nullptr);
         }

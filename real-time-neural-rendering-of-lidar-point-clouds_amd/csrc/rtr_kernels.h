@@ -109,6 +109,7 @@ struct StoreConsts {  // rarely needed, rarely changing: lives in the store's he
     uint64_t dyn_cap;
     uint32_t heavy, slice;        // split tiles with more entries than `heavy` into slices of >= `slice`
     uint32_t *err_host;           // mapped host word: T1's epilogue ORs a frame's tile-store error code into it
+    uint32_t *split_host;         // mapped host word: tiles above the split threshold in the frame T1 has just binned
 };
 // meta, in 32-bit words:
 //   fill[nst << kFillShiftMax]  stream length while T1 runs; zero between frames

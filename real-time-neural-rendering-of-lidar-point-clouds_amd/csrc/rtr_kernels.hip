@@ -506,7 +506,14 @@ __device__ __forceinline__ int stream_tile(const TileGeom &g, int tx, int ty, in
 //   first), frame statistics, the occupancy bitmap of the peer-to-peer exchange, pool / ticket reset.
 // Only when some tile exceeds the split threshold are its slices laid out (scans) and, if asked for,
 // its pixels reset.
-__device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split, uint32_t colour_chunks) {
+// flags: bit 0 = reset the pixels of the tiles that will be split (clear_split), bit 1 = split NO tile in this frame:
+// the host does not launch k_tile_split behind it -- it skips that launch while the frames it has seen complete had no
+// tile above the threshold (sc.split_host tells it, without a sync) -- so a tile that is above it after all is
+// processed by its one workgroup: slow, exact, and reported (next_frame_order), which brings the split launch back a
+// few frames later.
+__device__ void bin_epilogue(const TileStore &S, int W, int H, int flags, uint32_t colour_chunks) {
+    const int clear_split = flags & 1;
+    const bool no_split = (flags & 2) != 0;
     const TileGeom g = tile_geom(W, H);
     uint32_t *const fill = ts_fill(S), *const tile_cnt = ts_tile_cnt(S);
     uint32_t *const hdr = ts_hdr(S), *const hctr = ts_hctr(S);
@@ -517,7 +524,7 @@ __device__ void bin_epilogue(const TileStore &S, int W, int H, int clear_split, 
     const StoreConsts sc = *ts_consts(S);
     typedef uint32_t __attribute__((address_space(1))) *gu32_t;  // (pointers out of memory: global, not flat)
     const gu32_t depth = (gu32_t)sc.depth, acc = (gu32_t)sc.acc, occ = (gu32_t)sc.occ;
-    const uint32_t heavy = sc.heavy;
+    const uint32_t heavy = no_split ? 0xFFFFFFFFu : sc.heavy;
 #ifdef RTR_EXPERIMENT
     if (threadIdx.x == 0 && heavy != 7u) ts_dbg(S)[5] = wall_clock64();  // consts have arrived
 #endif
@@ -702,13 +709,23 @@ __device__ void next_frame_order(const TileStore &S) {
     uint32_t *const perm = ts_perm(S);
     const int t = threadIdx.x, nt = S.ntiles, step = blockDim.x;
     const uint32_t thr = 2u * (ts_hdr(S)[kHdrEntries] / (uint32_t)nt) + 1u;
-    uint32_t big = 0, all = 0;
+    const StoreConsts *const sc = ts_consts(S);
+    const uint32_t heavy = sc->heavy;
+    uint32_t big = 0, all = 0, over = 0;
     const int per = (nt + step - 1) / step, lo = t * per;  // contiguous tiles per thread: positions stay tile-ordered
     for (int k = 0; k < per; ++k)
         if (lo + k < nt) {
             all += 1;
             big += tile_cnt[lo + k] > thr ? 1u : 0u;
+            over += tile_cnt[lo + k] > heavy ? 1u : 0u;
         }
+    // Tiles above the split threshold in this frame -> a mapped host word: the host launches k_tile_split behind a
+    // whole frame only while this has been non-zero lately (rtr_ctx::split_host; read without a sync).
+    {
+        typedef uint32_t __attribute__((address_space(1))) *gu32_t;
+        const int any_over = __syncthreads_or(over != 0u);
+        if (t == 0 && sc->split_host) *(volatile gu32_t)sc->split_host = any_over ? 1u : 0u;
+    }
     uint32_t n_big = 0, n_all = 0;
     uint32_t big_before = block_scan(big, s_w, n_big) - big;
     uint32_t all_before = block_scan(all, s_w, n_all) - all;
@@ -2104,15 +2121,33 @@ void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int
     // (hipExtLaunchKernelGGL with null events is a plain launch; with events the dispatch packet itself carries
     // the start / stop time stamps: no extra packets around the kernel, unlike hipEventRecord pairs)
     const bool packed = c.pk.hdr != nullptr;
-    // (a packed chunk is ~1.5 KB in flight per wave instead of 3 KB: a fifth workgroup per CU pays, 161 -> 155 us;
-    // the kernel's 89 registers admit five waves per SIMD)
-    const dim3 grid(point_grid(n4, packed && c.grid == kDefaultPointGrid ? kDefaultPointGrid * 5 / 4 : c.grid)), block(kBlock);
+    const dim3 block(kBlock);
     const float4 *x = packed ? (const float4 *)c.pk.hdr : (const float4 *)c.x;
     const float4 *y = packed ? (const float4 *)c.pk.planes : (const float4 *)c.y, *z = (const float4 *)c.z;
     const uint4 *col = (const uint4 *)c.rgba;
+    // The default grid is what is RESIDENT at once (the kernel is a grid-stride loop over windows of the cloud: a
+    // workgroup that has to wait for a slot runs the whole loop as a second round).  A packed chunk is ~1.3 KB in flight
+    // per wave instead of 3 KB, so the packed kernels take a fifth workgroup per CU when their registers admit it (<= 96:
+    // a build at 100 registers launched with the fixed 1280 of before ran 170 instead of 140 us); asked of the runtime
+    // once per kernel.
+    auto default_grid = [&](auto kernel, int &cached) -> int {
+        if (cached == 0) {
+            int per_cu = 0, dev = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1)
+                cached = kDefaultPointGrid;
+            else
+                cached = cus * (per_cu < 4 ? per_cu : (packed && per_cu >= 5 ? 5 : 4));
+        }
+        return cached;
+    };
 #define RTR_T1(CULL, GROUPS, PACKED)                                                                                          \
-    hipExtLaunchKernelGGL((k_project_bin<CULL, GROUPS, PACKED>), grid, block, 0, s, ev_start, ev_stop, 0, x, y, z, col,        \
-                          (uint32_t)n4, P, W, H, S, bounds, clear_split, (uint32_t)phases, xp)
+    do {                                                                                                                      \
+        static int cached_grid = 0;                                                                                           \
+        const dim3 grid(point_grid(n4, c.grid == kDefaultPointGrid ? default_grid(k_project_bin<CULL, GROUPS, PACKED>, cached_grid) : c.grid)); \
+        hipExtLaunchKernelGGL((k_project_bin<CULL, GROUPS, PACKED>), grid, block, 0, s, ev_start, ev_stop, 0, x, y, z, col,    \
+                              (uint32_t)n4, P, W, H, S, bounds, clear_split, (uint32_t)phases, xp);                           \
+    } while (0)
     if (bounds) {
         if (packed) RTR_T1(true, true, true); else RTR_T1(true, true, false);
     } else if (c.incoherent) {

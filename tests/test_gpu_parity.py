@@ -612,6 +612,43 @@ def test_ten_million_points_in_one_tile(pkg, orc, projector):
     assert int(ref["acc"][..., 3].sum()) > 0
 
 
+def test_split_launch_is_skipped_until_a_frame_needs_it(pkg, orc, projector):
+    """Whole frames launch the split kernel only while tiles above the split threshold have been seen (a mapped host
+    word T1's epilogue writes; eight frames of grace after an upload).  After a run of ordinary frames the launch is off:
+    the first frame with a hot tile is then processed without it -- the tile by its one workgroup, exact -- and reported,
+    so the following frames get the split launch back; and off again after another run of ordinary frames."""
+    rng = np.random.default_rng(32)
+    n = 300_000
+    xyz = np.stack([rng.uniform(-0.05, 0.05, n), rng.uniform(-0.05, 0.05, n), rng.uniform(1.9, 2.1, n)], axis=1)
+    rgb = rng.integers(0, 256, size=(n, 3), dtype=np.uint8)
+    xyzw, rgba = cloud(xyz.astype(np.float32), rgb)
+    P_hot = kat_P(orc)                    # everything lands in a 10x10 pixel patch
+    K = np.array([[4000.0, 0, 32], [0, 4000.0, 24], [0, 0, 1]])
+    P_wide = orc.compose_projection(K, np.eye(4))  # zoomed in: spread over the whole 64x48 frame
+    projector.upload_points(xyzw, rgba)
+    projector.set_resolution(64, 48)
+    refs = {id(P): orc.project(xyzw, rgba, P, 64, 48) for P in (P_hot, P_wide)}
+    seen = []
+    for k, P in enumerate([P_wide] * 12 + [P_hot] * 3 + [P_wide] * 12 + [P_hot] * 2):
+        filtered = bool(k & 1)
+        img, depth = projector.project(P, filtered=filtered)
+        st = projector.frame_stats()
+        assert st["errors"] == 0, (k, st)
+        seen.append((P is P_hot, st["split_tiles"], st["heaviest_tile"]))
+        ref = refs[id(P)]
+        rd, ri = ref["depth_bits"], ref["img"]
+        if filtered:
+            rf = orc.filter(rd, ri)
+            rd, ri = rf["depth"].view(np.uint32), rf["img"]
+            assert np.array_equal(projector.download(pkg._lib.BUF_TENSOR).reshape(5, 48, 64), rf["tensor"]), k
+        assert np.array_equal(depth.view(np.uint32), rd), (k, seen)
+        assert np.array_equal(img, ri), (k, seen)
+    hot = [s for s in seen if s[0]]
+    assert all(h[2] > 32768 for h in hot), seen
+    # first hot frame of each run: no split launch behind it (no tile was split); the next ones: split again
+    assert hot[0][1] == 0 and hot[1][1] >= 1 and hot[2][1] >= 1 and hot[3][1] == 0 and hot[4][1] >= 1, seen
+
+
 def test_split_tile_with_a_single_slice(pkg, orc, projector):
     """Two hot tiles of very different weight: the slice size grows with the frame's split entries (at most 512 slice
     records), so the lighter tile is above the split threshold and still gets ONE slice -- its record goes through
