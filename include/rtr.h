@@ -76,7 +76,11 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *  "split_threshold" (default 32768; 0 = never), "split_slice" (default 16384): a screen tile
  *          holding more entries than the threshold is processed by several workgroups, each
  *          taking a slice of at least split_slice entries (a distant overview that packs the
- *          whole cloud into a few tiles would otherwise serialise on them).
+ *          whole cloud into a few tiles would otherwise serialise on them).  Whole-frame calls launch the
+ *          kernel that does this only while such tiles have been seen (the library learns it from the frames
+ *          that have completed, without a sync; eight frames of grace after an upload, a new resolution or a
+ *          change of these options): the first frame(s) of a view that suddenly packs the cloud into a few
+ *          tiles are therefore rendered unsplit -- exact, slower -- until the report arrives.
  *  "auto_reorder": what follows every later rtr_upload_points / rtr_generate_synthetic.  2 (default): the
  *          cloud is Morton-sorted once (rtr_reorder_points) when its 256-point chunks are not spatially
  *          compact -- mean chunk-box diagonal above twice what an ideally ordered volume cloud of that
@@ -108,7 +112,8 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          before "overlap") additionally gives the two streams disjoint CU masks, t CUs of every
  *          XCD for the tail.
  *  "point_grid": workgroups of the grid-stride point kernels (default 1024 = 4 per CU; at the default the
- *          tile-binned point kernel takes 1280 when it reads packed coordinates).
+ *          tile-binned point kernel takes what is resident at once: 5 per CU when it reads packed coordinates
+ *          and its registers admit it, else 4).
  *  "phases": the point kernel's workgroups are cut into this many groups that start at different
  *          places of the cloud (default 0 = automatic: 1, which keeps one dense streaming front, unless the
  *          previous frame had more than a quarter of the cloud inside the frustum, then 16 -- the claims of
