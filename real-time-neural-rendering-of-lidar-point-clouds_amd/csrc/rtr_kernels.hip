@@ -353,7 +353,10 @@ constexpr int kTileH = 32;
 #define RTR_TILE_WAVES 6
 #endif
 constexpr int kTileThreads = RTR_TILE_THREADS;
-constexpr int kTileThreadsCompact = 256;      // k_tile<0> (see tile_body)
+#ifndef RTR_TILE0_THREADS
+#define RTR_TILE0_THREADS 256
+#endif
+constexpr int kTileThreadsCompact = RTR_TILE0_THREADS;  // k_tile<0> (see tile_body)
 #ifndef RTR_TILE0_WAVES
 #define RTR_TILE0_WAVES 8
 #define RTR_TILE0_SWEEP 4
