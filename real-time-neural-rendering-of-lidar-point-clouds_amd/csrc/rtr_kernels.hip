@@ -991,8 +991,10 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
             bool gk[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                gk[k] = in[k] && grp[k] < 0 && st[k] == lead;
-                const unsigned long long m = __ballot(gk[k]);
+                // (pm[k] IS "in the frustum and not grouped yet": one compare, the rest on the scalar unit; the mask comes
+                // back as the lane's condition without a vector instruction)
+                const unsigned long long m = __ballot(st[k] == lead) & pm[k];
+                gk[k] = __builtin_amdgcn_inverse_ballot_w64(m);
                 lower += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 total += (uint32_t)__popcll(m);
                 pm[k] &= ~m;
