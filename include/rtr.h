@@ -118,9 +118,10 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          places of the cloud (default 0 = automatic: 1, which keeps one dense streaming front, unless the
  *          previous frame had more than a quarter of the cloud inside the frustum, then 16 -- the claims of
  *          a distant overview spread over more stream counters); "fill_shift": the per-tile stream counters
- *          lie 4 << value bytes apart (default 4 = 64 bytes; packed counters share memory channels and queue
- *          up: a distant overview with every point in a dozen tiles takes 3.0 ms in the point kernel at 2,
- *          1.5 ms at 4, for +1 % on an ordinary view).
+ *          lie 4 << value bytes apart (0..6; packed counters share memory channels and queue up: a distant
+ *          overview with every point in a dozen tiles takes 3.0 ms in the point kernel at 2, 1.5 ms at 4, for +1 %
+ *          on an ordinary view).  Default -1 = automatic: 1 (8 bytes) on ordinary frames, 4 (64 bytes) while frames
+ *          with tiles above "split_threshold" have been seen lately (and in the phase / sharded calls).
  *  "p2p_timeout_ms": how long a flag barrier of the peer-to-peer exchange (section 5b) waits for a rank
  *          that does not arrive before it flags the frame in rtr_p2p_status (default 2000).
  *  "debug_dyn_cap": test aid -- caps the pool of dynamic stream extents at this many entries (-1 = off), so that a

@@ -74,7 +74,7 @@ struct rtr_ctx {
     int opt_heavy = 32768;           // tiles with more entries are split over several workgroups in T4 ...
     int opt_slice = 16384;           // ... into slices of at least this many entries
     int opt_p2p_timeout_ms = 2000;   // peer-to-peer flag barriers give up after this long (option "p2p_timeout_ms")
-    int opt_fill_shift = 4;          // stream counters 2^4 words = 64 B apart (see "fill_shift")
+    int opt_fill_shift = -1;         // spacing of the stream counters, 4 << value bytes; -1: by the frames seen (see "fill_shift")
     int opt_debug_dyn_cap = -1;      // test aid: cap the dynamic extent pool at this many entries (-1: off)
     uint32_t *err_host = nullptr;    // mapped host word: tile-store error bits of frames since it was last read
     uint32_t *err_dev = nullptr;     // ... as the device sees it (StoreConsts::err_host)
@@ -651,7 +651,7 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
     }
 #endif
     if (!strcmp(key, "fill_shift")) {  // spacing of the tile stream counters: 4 << value bytes
-        NEED(c, value >= 0 && value <= rtr::kFillShiftMax, "fill_shift must be in 0..6");
+        NEED(c, value >= -1 && value <= rtr::kFillShiftMax, "fill_shift must be in -1..6 (-1: automatic)");
         DevGuard g(c->device);
         HIP_TRY(c, sync_streams(c));
         c->opt_fill_shift = value;  // (the counters are all zero between frames: any spacing can follow any other)
@@ -1042,7 +1042,11 @@ static int bin_points(rtr_ctx *c, const float P[16], bool overlapped, bool clear
     if (int rc = ensure_lists(c)) return rc;
     if (int rc = ensure_tiles(c, s1)) return rc;
     auto &t = c->F().store;
-    t.fill_shift = c->opt_fill_shift;
+    // (automatic: 8 bytes apart -- fewer cache lines for T1's epilogue to read and reset: -2 us on C3, -2.5 us on C2 --
+    // unless tiles above the split threshold have been seen lately, where the claims of all waves queue on a dozen
+    // counters and those want lines of their own; any spacing can follow any other, the counters are zero between frames)
+    const bool heavy_seen = c->split_cooldown > 0 || __atomic_load_n(c->split_host, __ATOMIC_RELAXED) != 0u;
+    t.fill_shift = c->opt_fill_shift >= 0 ? c->opt_fill_shift : (heavy_seen ? 4 : 1);
     t.seq = (t.seq + 1u) & 0xFFFFFFu;
     if (t.seq == 0u) {  // the 24-bit stamp wrapped: forget every directory entry once
         HIP_TRY(c, hipMemsetAsync(rtr::ts_dir(t), 0, (size_t)c->F().nst * rtr::kDirK * sizeof(unsigned long long), s1));

@@ -23,6 +23,13 @@ def timed(name):
         best = min(best, (time.perf_counter() - t0) / frames * 1e3)
     print("%-32s %.4f ms/frame" % (name, best), flush=True)
 timed("default")
+for fs in (0, 1, 2, 3, 4, 5):
+    p.set_option("fill_shift", fs)
+    timed("fill_shift %d" % fs)
+p.set_option("fill_shift", -1)
+if len(sys.argv) > 2 and sys.argv[2] == "fill":
+    p.close()
+    sys.exit(0)
 for ph in (2, 3, 4, 8, 16):
     p.set_option("phases", ph)
     timed("phases %d" % ph)
