@@ -279,7 +279,8 @@ int ensure_tiles(rtr_ctx *c, hipStream_t s) {
         f.consts = rtr::StoreConsts{};
         c->list_valid = false;
         const size_t meta_bytes = rtr::ts_meta_words(nst, nt) * sizeof(uint32_t);
-        HIP_TRY(c, hipMalloc((void **)&t.ext0, (size_t)nst * rtr::kS0 * sizeof(uint64_t)));
+        // (+ 16 entries of slack: the tile kernel's sweeps read a few entries past the piece they are masking)
+        HIP_TRY(c, hipMalloc((void **)&t.ext0, ((size_t)nst * rtr::kS0 + 16) * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&t.meta, meta_bytes));
         HIP_TRY(c, hipMemsetAsync(t.meta, 0, meta_bytes, s));  // stream lengths 0, directory stamps 0 (never current)
         t.seq = 0;

@@ -1849,12 +1849,13 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
                 const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seg_n[q]);  // (n >= 1)
                 const uint32_t pb = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seg_pb[q]);
                 unsigned long long ra[SB], rb[SB];
+                // (a thread's SB entries from ONE address: threads past the end re-read the piece's first entries, the
+                // last thread inside it reads up to SB - 1 entries past it -- inside the next extent, or inside the
+                // slack every allocation of entries ends with; both are masked by index in work())
                 auto fetch = [&](unsigned long long *dst, uint32_t base) __attribute__((always_inline)) {
+                    const uint32_t b = base + (uint32_t)tid * SB, bc = b < n ? b : 0u;
 #pragma unroll
-                    for (int k = 0; k < SB; ++k) {
-                        const uint32_t i = base + (uint32_t)tid * SB + k;
-                        dst[k] = ent[i < n ? i : n - 1u];
-                    }
+                    for (int k = 0; k < SB; ++k) dst[k] = ent[bc + k];
                 };
                 auto work = [&](const unsigned long long *src, uint32_t base) __attribute__((always_inline)) {
                     unsigned long long v[SB];
