@@ -364,6 +364,9 @@ constexpr int kTileThreadsCompact = RTR_TILE0_THREADS;  // k_tile<0> (see tile_b
 #ifndef RTR_TILE0_AHEAD
 #define RTR_TILE0_AHEAD 1
 #endif
+#ifndef RTR_TILE0_BATCH
+#define RTR_TILE0_BATCH 8
+#endif
 constexpr int kTileBatch = RTR_TILE_BATCH;    // entries in flight per thread in k_tile
 #ifndef RTR_T1_WAVES
 #define RTR_T1_WAVES 4  // the point kernel runs 4 waves per SIMD (1024 workgroups); capping it at 80 registers so that a
@@ -1455,6 +1458,8 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
     uint8_t *s_rgb = reinterpret_cast<uint8_t *>(s_mem + (kCompact ? 3 : 5) * tpix);  // [3 * tpix] (MODE 0, 3, 4)
     const int tid = threadIdx.x;
     constexpr uint32_t T = kCompact ? kTileThreadsCompact : kTileThreads;
+    constexpr int TB = kCompact ? RTR_TILE0_BATCH : kTileBatch;  // entries per thread of a one-batch tile
+    constexpr int TP2 = TB / 2, TP4 = TB / 4;                     // ... per stream of a 2- / 4-stream tile
     const int tw = 1 << g.tw_shift;
     // MODE 1 / 2, bit 1: this launch is the only writer of the frame buffer (no rtr_clear before it):
     // store the tile's depth / sums instead of folding them into what memory holds
@@ -1533,15 +1538,15 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
         // Register group q of a thread holds CONSECUTIVE entries of stream q.
         const int ns = 2 << (g.tw_shift - 5);  // streams
         const bool two = ns == 2;
-        const uint32_t lim = T * (two ? kPer2 : kPer4);  // (<= 2048 < kS0: inside the static extent)
-        static_assert(T * kPer2 <= kS0, "one batch must fit the static extent");
+        const uint32_t lim = T * (two ? TP2 : TP4);  // (<= 2048 < kS0: inside the static extent)
+        static_assert(T * TP2 <= kS0, "one batch must fit the static extent");
         const bool one_batch = (MODE == 0 || (MODE == 4 && occ4 == (1u << dsl.rank))) && !split && rec0.y <= lim && rec0.z <= lim &&
                                (ns == 2 || (rec0.w <= lim && rec1.x <= lim));
-        unsigned long long r[kTileBatch];
+        unsigned long long r[TB];
         auto load_batch = [&](auto per_tag) {  // (compile-time register -> stream mapping: everything stays in registers)
             constexpr int PER = decltype(per_tag)::value;
 #pragma unroll
-            for (int q = 0; q < kTileBatch / PER; ++q) {
+            for (int q = 0; q < TB / PER; ++q) {
                 const int st = stream_tile(g, tx, ty, q);
                 const entries_t src = (entries_t)(S.ext0 + ((size_t)(st >= 0 ? st : 0) << kS0Shift));
                 const uint32_t cq = q == 0 ? rec0.y : (q == 1 ? rec0.z : (q == 2 ? rec0.w : rec1.x));
@@ -1556,8 +1561,8 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
             }
         };
         if (one_batch) {
-            if (two) load_batch(std::integral_constant<int, kPer2>{});
-            else load_batch(std::integral_constant<int, kPer4>{});
+            if (two) load_batch(std::integral_constant<int, TP2>{});
+            else load_batch(std::integral_constant<int, TP4>{});
         }
         auto stream_pb = [&](int q) -> uint32_t {  // where stream q's 32x16 storage tile sits in the processing tile
             const int per_row = 1 << (g.tw_shift - 5);
@@ -1702,13 +1707,13 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
         // can only cause a redundant atomic.)
         auto min_runs = [&](auto per_tag) {
             constexpr int PER = decltype(per_tag)::value;
-            uint32_t pix[kTileBatch], cur[kTileBatch];
+            uint32_t pix[TB], cur[TB];
 #pragma unroll
-            for (int k = 0; k < kTileBatch; ++k) pix[k] = pixel_of(r[k], stream_pb(k / PER));
+            for (int k = 0; k < TB; ++k) pix[k] = pixel_of(r[k], stream_pb(k / PER));
 #pragma unroll
-            for (int k = 0; k < kTileBatch; ++k) cur[k] = __hip_atomic_load(&s_mem[pix[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int k = 0; k < TB; ++k) cur[k] = __hip_atomic_load(&s_mem[pix[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-            for (int k0 = 0; k0 < kTileBatch; k0 += PER) {
+            for (int k0 = 0; k0 < TB; k0 += PER) {
                 uint32_t run_p = pix[k0], run_d = (uint32_t)(r[k0] >> 33), run_c = cur[k0];
 #pragma unroll
                 for (int j = 1; j < PER; ++j) {
@@ -1740,18 +1745,18 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
                     }
                 }
             };
-            uint32_t pix[kTileBatch];
-            float m[kTileBatch];
+            uint32_t pix[TB];
+            float m[TB];
 #pragma unroll
-            for (int k = 0; k < kTileBatch; ++k) pix[k] = pixel_of(r[k], stream_pb(k / PER));
+            for (int k = 0; k < TB; ++k) pix[k] = pixel_of(r[k], stream_pb(k / PER));
 #pragma unroll
-            for (int k = 0; k < kTileBatch; ++k) m[k] = __uint_as_float(s_mem[pix[k]]);  // s_depth: final since the barrier
+            for (int k = 0; k < TB; ++k) m[k] = __uint_as_float(s_mem[pix[k]]);  // s_depth: final since the barrier
             auto value_of = [&](unsigned long long e, float mk) -> unsigned long long {
                 if (__uint_as_float((uint32_t)(e >> 33)) > f_add(mk, window)) return 0ull;  // render.cu:106, then :125-128
                 return (e & 0xFFull) | (((e >> 8) & 0xFFull) << 16) | (((e >> 16) & 0xFFull) << 32) | (1ull << 48);
             };
 #pragma unroll
-            for (int k0 = 0; k0 < kTileBatch; k0 += PER) {
+            for (int k0 = 0; k0 < TB; k0 += PER) {
                 uint32_t run_p = pix[k0];
                 unsigned long long run_v = value_of(r[k0], m[k0]);
 #pragma unroll
@@ -1775,7 +1780,7 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
         // registers: one LDS atomic per run instead of one per entry (the two passes of a C3 tile are LDS-atomic bound:
         // 8 resident tiles x 3.3 k entries per CU and pass).  The loads are unconditional from clamped indices (a
         // load whose result merges with a constant is waited for on the spot) and masked when they are used.
-        constexpr int SB = kCompact ? RTR_TILE0_SWEEP : kTileBatch;  // entries per thread and buffer
+        constexpr int SB = kCompact ? RTR_TILE0_SWEEP : TB;  // entries per thread and buffer
         constexpr bool kSweepAhead = kCompact ? (RTR_TILE0_AHEAD != 0) : true;
         auto min_seq = [&](const unsigned long long *v, uint32_t pb) __attribute__((always_inline)) {
             uint32_t pix[SB], cur[SB];
@@ -1885,8 +1890,8 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
             if (stamp && tid == 0 && r[0] != 1ull) ts_dbg(S)[sb + 11] = wall_clock64();  // first entry has arrived
             if (stamp && tid == 0 && (r[3] ^ r[7]) != 1ull) ts_dbg(S)[sb + 12] = wall_clock64();  // all have
 #endif
-            if (two) min_runs(std::integral_constant<int, kPer2>{});
-            else min_runs(std::integral_constant<int, kPer4>{});
+            if (two) min_runs(std::integral_constant<int, TP2>{});
+            else min_runs(std::integral_constant<int, TP4>{});
         } else if (do_min) {
             sweep([&](const unsigned long long *v, uint32_t pb) __attribute__((always_inline)) { min_seq(v, pb); }, kPadMin);
         }
@@ -1895,8 +1900,8 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
         RTR_TSTAMP(3);
         auto accumulate = [&](bool packed) __attribute__((always_inline)) {
             if (one_batch) {
-                if (two) acc_runs(std::integral_constant<int, kPer2>{}, packed);
-                else acc_runs(std::integral_constant<int, kPer4>{}, packed);
+                if (two) acc_runs(std::integral_constant<int, TP2>{}, packed);
+                else acc_runs(std::integral_constant<int, TP4>{}, packed);
                 return;
             }
             sweep([&](const unsigned long long *v, uint32_t pb) __attribute__((always_inline)) { acc_seq(v, pb, packed); }, kPadAcc);
@@ -2034,7 +2039,7 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
                             // (this rare path must not shape the kernel: everything a one-batch tile derives from its
                             // registers is invariant over the two halves, and hoisted out of this loop it spilled)
 #pragma unroll
-                            for (int k = 0; k < kTileBatch; ++k) asm volatile("" : "+v"(r[k]));
+                            for (int k = 0; k < TB; ++k) asm volatile("" : "+v"(r[k]));
                         }
                         for (int p = tid; p < (kCompact ? 2 : 4) * tpix; p += T) s_acc[p] = 0;
                         __syncthreads();
