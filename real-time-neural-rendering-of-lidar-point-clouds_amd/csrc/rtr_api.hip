@@ -31,6 +31,9 @@ struct rtr_ctx {
     float *x = nullptr, *y = nullptr, *z = nullptr;
     uint32_t *rgba = nullptr;
     float *bounds = nullptr;    // bounding box per 256-point chunk (frustum culling option)
+    float *spread = nullptr;    // lane spread per 256-point chunk (rtr::Cloud::spread: T1's lane test)
+    float absmax[3] = {0.f, 0.f, 0.f};  // largest finite |x|, |y|, |z| of the resident cloud
+    int opt_lane_test = 1;      // T1 tests one point per lane first (option "lane_test")
     uint64_t n = 0, cap = 0;
     uint4 *pk_hdr = nullptr;        // rtr::PackedXyz of the resident cloud (option "pack"); null: not in use
     uint32_t *pk_planes = nullptr;
@@ -261,7 +264,7 @@ void free_pack(rtr_ctx *c) {
 }
 
 void free_cloud(rtr_ctx *c) {
-    dfree(c->x); dfree(c->y); dfree(c->z); dfree(c->rgba); dfree(c->bounds);
+    dfree(c->x); dfree(c->y); dfree(c->z); dfree(c->rgba); dfree(c->bounds); dfree(c->spread);
     free_pack(c);
     free_lists(c);
     c->n = c->cap = 0;
@@ -335,6 +338,7 @@ int alloc_cloud(rtr_ctx *c, uint64_t n) {
         HIP_TRY(c, hipMalloc((void **)&c->z, n_pad * 4));
         HIP_TRY(c, hipMalloc((void **)&c->rgba, n_pad * 4));
         HIP_TRY(c, hipMalloc((void **)&c->bounds, ((n_pad / 4 + 63) / 64) * 6 * sizeof(float)));
+        HIP_TRY(c, hipMalloc((void **)&c->spread, ((n_pad / 4 + 63) / 64) * sizeof(float)));
         c->cap = n_pad;
     }
     c->n = n;
@@ -354,7 +358,7 @@ rtr::Cloud cloud_of(const rtr_ctx *c) {
     // cloud measures ~1.0; the reference loader's 0.25 m blocks in hash-map order, unordered inside, measure 0.28 for a
     // 10 m room and must keep the wave-level claim groups: 0.33 ms instead of 0.66 ms per frame without them)
     return rtr::Cloud{c->x, c->y, c->z, c->rgba, c->n, c->opt_grid, (!c->reordered && c->order_ratio > 0.5f) ? 1 : 0,
-                      rtr::PackedXyz{c->pk_hdr, c->pk_planes}};
+                      rtr::PackedXyz{c->pk_hdr, c->pk_planes}, c->spread, {c->absmax[0], c->absmax[1], c->absmax[2]}};
 }
 
 struct Timed {  // brackets one phase with hipEvents on the stream it is launched on
@@ -692,6 +696,11 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
         c->opt_cull = value != 0;
         return RTR_OK;
     }
+    if (!strcmp(key, "lane_test")) {  // T1: one point per lane first (k_project_bin); 0 = every point, as in round 3
+        c->opt_lane_test = value != 0;
+        c->list_valid = false;
+        return RTR_OK;
+    }
     if (!strcmp(key, "pack")) {  // applies to the resident cloud at once, and to every later one
         NEED(c, value >= 0 && value <= 2, "pack must be 0 (never), 1 (when it pays) or 2 (always, verified)");
         c->opt_pack = value;
@@ -725,6 +734,7 @@ int rtr_get_option(rtr_ctx *c, const char *key, int *value) {
     else if (!strcmp(key, "reordered")) *value = c->reordered ? 1 : 0;  // the resident cloud was sorted by the library
     else if (!strcmp(key, "order_ratio_ppm")) *value = (int)(c->order_ratio * 1e6f);  // chunk / cloud diagonal as uploaded
     else if (!strcmp(key, "cull")) *value = c->opt_cull;
+    else if (!strcmp(key, "lane_test")) *value = c->opt_lane_test;
     else if (!strcmp(key, "pack")) *value = c->opt_pack;
     else if (!strcmp(key, "packed")) *value = c->pk_hdr ? 1 : 0;  // the point kernel reads the packed coordinates
     else if (!strcmp(key, "packed_millibytes_per_point"))         // its coordinate stream, headers included (12000 = raw)
@@ -841,18 +851,20 @@ static int pack_cloud(rtr_ctx *c) {
 static int auto_reorder(rtr_ctx *c) {
     c->reordered = false;
     c->order_ratio = 0.f;
-    if (c->n < 2) return RTR_OK;
+    c->absmax[0] = c->absmax[1] = c->absmax[2] = __builtin_inff();  // (unknown: the lane test's margin step stays off)
+    if (c->n < 1) return RTR_OK;
+    float ratio = 0.f;  // measured under every policy: the point kernel has a form for incoherent clouds
+    if (rtr::order_quality(c->stream, c->bounds, c->n, &ratio, c->absmax) != 0) {
+        (void)hipGetLastError();
+        c->absmax[0] = c->absmax[1] = c->absmax[2] = __builtin_inff();
+        return RTR_OK;
+    }
     bool want = c->opt_auto_reorder == 1;
     if (c->n >= (1u << 16)) {  // (tiny clouds render in microseconds whatever their order)
-        float ratio = 0.f;     // measured under every policy: the point kernel has a form for incoherent clouds
-        if (rtr::order_quality(c->stream, c->bounds, c->n, &ratio) != 0) {
-            (void)hipGetLastError();
-            return RTR_OK;
-        }
         c->order_ratio = ratio;
         if (c->opt_auto_reorder == 2) want = ratio > 2.0f * cbrtf(256.0f / (float)c->n);
     }
-    if (!want) return RTR_OK;
+    if (c->n < 2 || !want) return RTR_OK;
     if (rtr_reorder_points(c) != RTR_OK) (void)hipGetLastError();
     return RTR_OK;
 }
@@ -887,7 +899,7 @@ int rtr_upload_points(rtr_ctx *c, const float *xyz, size_t xs, const uint8_t *rg
         HIP_TRY(c, sync_streams(c));
     }
     rtr::launch_pad_nan(c->stream, c->x, c->y, c->z, c->rgba, n, (n + 3) & ~3ull);
-    rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
+    rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds, c->spread);
     HIP_TRY(c, sync_streams(c));
     if (int rc2 = launch_check(c, "aos_to_soa")) return rc2;
     free_pack(c);
@@ -907,7 +919,7 @@ int rtr_generate_synthetic(rtr_ctx *c, int scene, uint64_t seed, uint64_t first,
     if (rc) return rc;
     rtr::launch_generate(c->stream, scene, seed, first, count, total, c->x, c->y, c->z, c->rgba);
     rtr::launch_pad_nan(c->stream, c->x, c->y, c->z, c->rgba, count, (count + 3) & ~3ull);
-    rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
+    rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds, c->spread);
     HIP_TRY(c, sync_streams(c));
     if (int rc2 = launch_check(c, "generate")) return rc2;
     free_pack(c);
@@ -924,7 +936,7 @@ int rtr_reorder_points(rtr_ctx *c) {
     if (e != 0) return fail(c, RTR_ERR_HIP, "reorder failed: %s", hipGetErrorString((hipError_t)e));
     c->reordered = true;
     free_pack(c);
-    rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds);
+    rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds, c->spread);
     HIP_TRY(c, sync_streams(c));
     if (int rc = launch_check(c, "reorder")) return rc;
     return pack_cloud(c);
@@ -1056,7 +1068,8 @@ static int bin_points(rtr_ctx *c, const float P[16], bool overlapped, bool clear
     {
         Timed tm(c, RTR_K_MIN_DEPTH, s1, true);
         rtr::launch_project_bin(s1, cloud_of(c), make_proj(P), c->W, c->H, t, c->opt_cull ? c->bounds : nullptr,
-                                (clear_split ? 1 : 0) | (no_split ? 2 : 0), c->opt_phases, c->opt_xp, tm.a, tm.b);
+                                (clear_split ? 1 : 0) | (no_split ? 2 : 0) | (c->opt_lane_test ? 0 : 4), c->opt_phases, c->opt_xp,
+                                tm.a, tm.b);
         c->p2p.occ_from_scan = c->p2p.open;
     }
     if (overlapped) {

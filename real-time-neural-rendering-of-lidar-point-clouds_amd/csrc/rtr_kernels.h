@@ -22,7 +22,7 @@ struct Proj {
 // at bit 4 b l): 32 b bytes, read with ONE dword-aligned 16-byte load per lane (the lane shifts its data down by
 // the 0..28 bits its first value starts into that dword); a chunk is its x, y, z blocks.
 // hdr[2 c] = {base x, base y, base z, bx | by << 6 | bz << 12 | kPackWideFlag if some b is 32},
-// hdr[2 c + 1] = {first 32-byte unit (lo, hi), 0, 0}.
+// hdr[2 c + 1] = {first 32-byte unit (lo, hi), lane spread of the chunk (fp32 bits, see Cloud::spread), 0}.
 // The buffer ends with spare bytes (the last lanes' 16-byte loads run past their values).
 // Spatially ordered clouds need 16-21 bits per coordinate (neighbours share sign, exponent and leading
 // mantissa bits): 5-8 B/pt instead of 12 (round 2 stored whole bytes: 6.5-9.2 B/pt).
@@ -40,6 +40,12 @@ struct Cloud {
     int grid;                // workgroups of the grid-stride point kernels
     int incoherent;          // consecutive points are unrelated (measured at upload): no wave-level claim groups
     PackedXyz pk;            // the same coordinates, packed (only read by launch_project_bin)
+    // Lane spread (k_chunk_bounds): per 256-point chunk the largest |coordinate difference| between a lane's FIRST
+    // point (4 l) and its other three (4 l + 1 .. 4 l + 3), over lanes and axes -- +inf when the chunk holds a
+    // non-finite or huge (> 1e30) coordinate.  T1 tests one point per lane and bounds the other three by it (see
+    // k_project_bin, "lane test").  null: no lane test.  absmax: largest finite |x|, |y|, |z| of the cloud.
+    const float *spread;
+    float absmax[3];
 };
 
 struct FilterLevels {
@@ -207,16 +213,17 @@ int storage_tile_count(int W, int H);  // 32x16 storage tiles
 void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const TileStore &S,
                         const float *bounds, int clear_split, int phases, int xp = 0, hipEvent_t ev_start = nullptr,
                         hipEvent_t ev_stop = nullptr);  // ev_*: time stamps taken by the dispatch itself (timing on)
-void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds);  // 6 floats per 256 points
+void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds, float *spread);  // 6 floats (+ 1) per 256 points
 // packing (see PackedXyz): pack_measure fills hdr[2 nchunks] (bases, widths, block offsets by an exclusive
 // scan) and *total_planes (device; in 32-byte units); pack_write fills the blocks; pack_verify counts the points whose decoded
 // coordinates differ from the raw ones (must be 0) into *mismatches (device).  nchunks = ceil(ceil(n / 4) / 64).
-void pack_measure(hipStream_t s, const Cloud &c, uint4 *hdr, uint32_t *chunk_planes, uint64_t *total_planes);
+void pack_measure(hipStream_t s, const Cloud &c, uint4 *hdr, uint32_t *chunk_planes, uint64_t *total_planes);  // (c.spread -> hdr[2 c + 1].z)
 void pack_write(hipStream_t s, const Cloud &c, const uint4 *hdr, uint32_t *planes);
 void pack_verify(hipStream_t s, const Cloud &c, const uint4 *hdr, const uint32_t *planes, uint64_t *mismatches);
 int reorder_morton(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, uint64_t n);  // rtr_reorder.hip
 // mean diagonal of the 256-point chunk boxes / diagonal of the cloud's box, from launch_chunk_bounds' output
-int order_quality(hipStream_t s, const float *bounds, uint64_t n, float *ratio);
+// absmax[3]: the largest finite |x|, |y|, |z| over the chunk boxes (+inf when no chunk has a finite box)
+int order_quality(hipStream_t s, const float *bounds, uint64_t n, float *ratio, float absmax[3]);
 // T4: per-tile LDS z-buffer over the tile store.  mode 0 = whole frame (min + accumulate + resolve
 // of every unsplit tile, min phase of split tiles), 3 = second phase of the split tiles of a whole
 // frame, 1 = min only, 2 = accumulate only, 4 = owner-computes sharded frame: like 0, but only the tiles

@@ -848,13 +848,52 @@ __device__ __forceinline__ void unpack_chunk(const ChunkRaw &c, uint32_t widths,
 // PACKED: the coordinates come from the PackedXyz form (x4 = its headers, y4 = its planes, z4 unused): 6-9
 // bytes per point instead of 12 for spatially ordered clouds.  A chunk's header is requested one iteration
 // before its planes, the planes one iteration before they are decoded.
+//
+// LANE TEST (the light path of every chunk).  The kernel is bound by the instructions it issues, not by HBM, and
+// nine chunks in ten hold no point inside the frustum: decoding and projecting all 256 points of such a chunk only to
+// discard them was two thirds of its instructions.  So a lane first decodes and projects ONE of its four points (the
+// first: 4 l) and bounds the other three by the chunk's LANE SPREAD s (Cloud::spread: no coordinate of points
+// 4 l + 1 .. 4 l + 3 differs from point 4 l's by more than s, measured when the cloud is uploaded): every row of the
+// matrix is linear, so |row(p_k) - row(p_0)| <= (|m0| + |m1| + |m2|) s.  With M one of the four margins of the
+// conservative test above (r.x + 0.75 r.z, (W + 0.25) r.z - r.x, same in y):
+//   the lane holds no point in front of the camera    when r.z(p_0) + lz s <= 0,
+//   the lane holds no point inside the frustum         when M(p_0) + lall s < 0 for some margin,
+// lz / lall the L1 norms of the rows involved (host: lane_test_consts).  The margin step transfers a bound from p_0 to
+// p_k through REAL arithmetic, while the exact test of p_k runs on its ROUNDED rows: the rows' rounding errors
+// (<= 4 x 2^-24 of their term magnitudes each) must stay below the margins' 0.25 px = 0.25 r.z, hence it is only applied
+// when every point of the lane has r.z > zsafe = 2^-17 x (bound of the rows' term magnitudes over the cloud's
+// bounding box) -- ~0.1-0.3 m for a room and a 1080p camera; nearer lanes just stay candidates.  A chunk with any
+// candidate lane takes the full path below (all four points per lane, the exact arithmetic decides as before), so
+// frames stay bit-identical; chunks with a non-finite or huge coordinate carry s = +inf and always take it.
+struct LaneTest {
+    float lz, lall, zsafe;
+};
+static LaneTest lane_test_consts(const Proj &P, int W, int H, const float absmax[3]) {
+    LaneTest t;
+    const float *m = P.m;
+    const float l1x = fabsf(m[0]) + fabsf(m[1]) + fabsf(m[2]), l1y = fabsf(m[4]) + fabsf(m[5]) + fabsf(m[6]);
+    const float l1z = fabsf(m[8]) + fabsf(m[9]) + fabsf(m[10]);
+    const float hi = (float)(W > H ? W : H) + 0.25f;
+    t.lz = l1z * 1.001f;
+    t.lall = ((l1x > l1y ? l1x : l1y) + hi * l1z) * 1.001f;
+    auto mag = [&](int r) { return fabsf(m[4 * r]) * absmax[0] + fabsf(m[4 * r + 1]) * absmax[1] + fabsf(m[4 * r + 2]) * absmax[2] + fabsf(m[4 * r + 3]); };
+    const float rx = mag(0), ry = mag(1), rz = mag(2);
+    t.zsafe = 0x1p-17f * ((rx > ry ? rx : ry) + hi * rz);
+    if (!(t.zsafe >= 1e-30f)) t.zsafe = __builtin_inff();  // (NaN / no finite box: the margin step never applies)
+    if (!(t.lz < 3e38f) || !(t.lall < 3e38f)) t.zsafe = __builtin_inff(), t.lz = t.lall = 3e38f;
+    return t;
+}
+
 template <bool CULL, bool GROUPS, bool PACKED>
 __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
                                                         const float4 *__restrict__ z4,
                                                         const uint4 *__restrict__ rgba4, uint32_t n4, Proj P, int W,
                                                         int H, TileStore S, const float *__restrict__ bounds,
-                                                        int clear_split, uint32_t cblock, int xp) {
+                                                        int clear_split, uint32_t cblock, int xp, LaneTest lt) {
     (void)xp;
+    // (!CULL: `bounds` carries the chunks' lane spreads of an unpacked cloud, or null; the packed form has them in its headers)
+    const float *const spread = CULL ? nullptr : bounds;
+    const bool lane_test = (clear_split & 4) == 0;
     const uint4 *const pk_hdr = reinterpret_cast<const uint4 *>(x4);
     const uint32_t *const pk_planes = reinterpret_cast<const uint32_t *>(y4);
     const float fW = (float)W, fH = (float)H;
@@ -911,6 +950,30 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
         r.X = X, r.Y = Y, r.Z = Z;
 #pragma unroll
         for (int k = 0; k < 4; ++k) r.rz[k] = f_add(fmaf(RTR_M(10), zs[k], fmaf(RTR_M(9), ys[k], f_mul(RTR_M(8), xs[k]))), RTR_M(11));
+    };
+    // the lane test on a lane's first point (see above); wave-uniform result: does any lane stay a candidate
+    auto lane_maybe = [&](float x0, float y0, float z0, float sp, bool live) -> bool {
+        const float rz0 = f_add(fmaf(RTR_M(10), z0, fmaf(RTR_M(9), y0, f_mul(RTR_M(8), x0))), RTR_M(11));
+        const float sz = f_mul(sp, lt.lz);
+        const bool front = live && (f_add(rz0, sz) > 0.0f);
+        if (__ballot(front) == 0ull) return false;
+        const float rx0 = f_add(fmaf(RTR_M(2), z0, fmaf(RTR_M(1), y0, f_mul(RTR_M(0), x0))), RTR_M(3));
+        const float ry0 = f_add(fmaf(RTR_M(6), z0, fmaf(RTR_M(5), y0, f_mul(RTR_M(4), x0))), RTR_M(7));
+        const float m = fminf(fminf(fmaf(hiW, rz0, -rx0), fmaf(hiH, rz0, -ry0)), fminf(fmaf(0.75f, rz0, rx0), fmaf(0.75f, rz0, ry0)));
+        const bool out = (int)(f_sub(rz0, sz) > lt.zsafe) & (int)(m < -f_mul(sp, lt.lall));  // (no branch)
+        return __ballot(front && !out) != 0ull;
+    };
+    // a lane's first value of an axis block (b <= 25; b = 0: the mask is empty, the value is the base)
+    auto first_value = [&](const AxisRaw &r, uint32_t b, uint32_t base) -> float {
+        uint32_t vbase = base, x;
+        asm("" : "+v"(vbase));
+        uint32_t sh;  // 4 b l; alignbit takes its low five bits.  (Written out: the compiler drops the mask on b, then no
+                      // longer knows the factor to be small and emits the quarter-rate 32-bit multiply.)
+        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(sh) : "s"(b << 2), "v"(lane));
+        const uint32_t e0 = __builtin_amdgcn_alignbit(r.d[1], r.d[0], sh);
+        const uint32_t mask = (1u << b) - 1u;
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(x) : "v"(e0), "s"(mask), "v"(vbase));
+        return __uint_as_float(x);
     };
     uint32_t n_colour = 0;  // chunks of this wave whose colours were loaded (frame statistics)
     auto do_quad = [&](uint32_t i, bool live, const Rows &r) {
@@ -1096,7 +1159,7 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
         // straight-line code and waits for the chunk's three loads exactly once, where they are decoded.
         ChunkRaw raw;
         uint4 h0, h1;
-        uint32_t hc = 0, bx = 0, by = 0, bz = 0, ww = 0, i = 0;
+        uint32_t hc = 0, bx = 0, by = 0, bz = 0, ww = 0, i = 0, spb = 0;
         bool hvalid = false, live = false;
         auto fetch_hdr = [&](uint32_t q) {
             const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(q < R ? chunk_of(q) : nchunks));
@@ -1109,7 +1172,7 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
             i = hc * 64u + (uint32_t)lane;
             live = hvalid && i < n4;
             i = i < n4 ? i : n4 - 1u;  // (masked lanes: any valid address for the colour load)
-            bx = h0.x, by = h0.y, bz = h0.z, ww = h0.w;
+            bx = h0.x, by = h0.y, bz = h0.z, ww = h0.w, spb = h1.z;
             raw = load_chunk(pk_planes, h0, h1, lane);
         };
         fetch_hdr(0);
@@ -1131,10 +1194,21 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
                 continue;
             }
 #endif
-            unpack_chunk(raw, ww, bx, by, bz, X, Y, Z, lane);
-            project_rows(X, Y, Z, r);
+            // lane test: one point per lane; (wave-uniform) chunks with a 32-bit axis or without a finite spread skip it
+            bool cand = true;
+            const uint32_t sp_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)spb);
+            if (lane_test && !(ww & kPackWideFlag) && sp_c < 0x7F000000u) {
+                const float x0 = first_value(raw.a[0], ww & 63u, bx), y0 = first_value(raw.a[1], (ww >> 6) & 63u, by);
+                const float z0 = first_value(raw.a[2], (ww >> 12) & 63u, bz);
+                cand = lane_maybe(x0, y0, z0, __uint_as_float(sp_c), live_c);
+            }
+            if (cand) {
+                unpack_chunk(raw, ww, bx, by, bz, X, Y, Z, lane);
+                project_rows(X, Y, Z, r);
+            }
             fetch_planes();
             fetch_hdr(q + 2);
+            if (!cand) continue;
 #ifdef RTR_EXPERIMENT
             if (RTR_XP(256)) {  // ... + decode + the three matrix rows
                 xp_sink ^= __float_as_uint(r.rz[0]) ^ __float_as_uint(r.rz[1]) ^ __float_as_uint(r.rz[2]) ^ __float_as_uint(r.rz[3]);
@@ -1153,15 +1227,16 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
         // flight, which is what keeps HBM busy with only 4 waves per SIMD.  Lanes past the end of the cloud
         // re-read its last quad and are masked (`live`).
         float4 X = make_float4(0.f, 0.f, 0.f, 0.f), Y = X, Z = X;
-        uint32_t i = 0;
+        uint32_t i = 0, spb = 0x7F800000u;
         bool have = false, live = false;
         auto fetch = [&](uint32_t q) {
-            const uint32_t c = q < R ? chunk_of(q) : nchunks;
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(q < R ? chunk_of(q) : nchunks));
             have = c < nchunks;  // wave-uniform
             if (have) {
                 i = c * 64u + (uint32_t)lane;
                 live = i < n4;
                 const uint32_t ic = live ? i : n4 - 1u;
+                if (spread) spb = __float_as_uint(spread[c]);  // (a scalar load, in flight with the coordinates)
                 X = ld_stream(x4 + ic);
                 Y = ld_stream(y4 + ic);
                 Z = ld_stream(z4 + ic);
@@ -1172,9 +1247,12 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
             Rows r;
             const bool have_c = have, live_c = live;
             const uint32_t i_c = i < n4 ? i : n4 - 1u;  // (masked lanes past the end: any valid address for the colour load)
-            if (have_c) project_rows(X, Y, Z, r);
+            bool cand = have_c;
+            if (have_c && lane_test && spread && spb < 0x7F000000u)
+                cand = lane_maybe(X.x, Y.x, Z.x, __uint_as_float(spb), live_c);  // (the lane test: one point per lane)
+            if (cand) project_rows(X, Y, Z, r);
             fetch(q + 1);
-            if (have_c) do_quad(i_c, live_c, r);
+            if (cand) do_quad(i_c, live_c, r);
         }
     } else {
         // 64 of the wave's chunks are tested at once, one per lane, then only the survivors are
@@ -2132,6 +2210,7 @@ void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int
     // (hipExtLaunchKernelGGL with null events is a plain launch; with events the dispatch packet itself carries
     // the start / stop time stamps: no extra packets around the kernel, unlike hipEventRecord pairs)
     const bool packed = c.pk.hdr != nullptr;
+    const LaneTest lt = lane_test_consts(P, W, H, c.absmax);
     const dim3 block(kBlock);
     const float4 *x = packed ? (const float4 *)c.pk.hdr : (const float4 *)c.x;
     const float4 *y = packed ? (const float4 *)c.pk.planes : (const float4 *)c.y, *z = (const float4 *)c.z;
@@ -2157,7 +2236,8 @@ void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int
         static int cached_grid = 0;                                                                                           \
         const dim3 grid(point_grid(n4, c.grid == kDefaultPointGrid ? default_grid(k_project_bin<CULL, GROUPS, PACKED>, cached_grid) : c.grid)); \
         hipExtLaunchKernelGGL((k_project_bin<CULL, GROUPS, PACKED>), grid, block, 0, s, ev_start, ev_stop, 0, x, y, z, col,    \
-                              (uint32_t)n4, P, W, H, S, bounds, clear_split, (uint32_t)phases, xp);                           \
+                              (uint32_t)n4, P, W, H, S, CULL ? bounds : (packed ? nullptr : c.spread), clear_split,          \
+                              (uint32_t)phases, xp, lt);                                                                      \
     } while (0)
     if (bounds) {
         if (packed) RTR_T1(true, true, true); else RTR_T1(true, true, false);
@@ -2171,15 +2251,18 @@ void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int
 
 // bounding box of every 256-point chunk (the unit one wave of T1 handles per iteration):
 // bounds[6 c .. 6 c + 5] = min x, y, z, max x, y, z; NaN padding is ignored.
+// spread[c] = the chunk's lane spread (Cloud::spread): max over lanes, axes and k = 1..3 of |v[4 l + k] - v[4 l]|,
+// rounded up; +inf when the chunk holds a NaN / infinite / huge coordinate (such a chunk never takes T1's lane test).
 __global__ __launch_bounds__(kBlock) void k_chunk_bounds(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
                                                          const float4 *__restrict__ z4, uint64_t n4,
-                                                         float *__restrict__ bounds) {
+                                                         float *__restrict__ bounds, float *__restrict__ spread) {
     const uint64_t nchunks = (n4 + 63) / 64;
     const int lane = threadIdx.x & 63;
     const float inf = __uint_as_float(0x7F800000u);
     for (uint64_t c = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6; c < nchunks;
          c += ((uint64_t)gridDim.x * kBlock) >> 6) {
         float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+        float sp = 0.f;
         uint64_t i = c * 64 + lane;
         if (i < n4) {
             const float4 v[3] = {x4[i], y4[i], z4[i]};
@@ -2187,6 +2270,10 @@ __global__ __launch_bounds__(kBlock) void k_chunk_bounds(const float4 *__restric
             for (int k = 0; k < 3; ++k) {
                 lo[k] = fminf(fminf(v[k].x, v[k].y), fminf(fminf(v[k].z, v[k].w), lo[k]));  // fminf ignores NaN
                 hi[k] = fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(fmaxf(v[k].z, v[k].w), hi[k]));
+                const float d1 = fabsf(v[k].y - v[k].x), d2 = fabsf(v[k].z - v[k].x), d3 = fabsf(v[k].w - v[k].x);
+                const float a = fmaxf(fmaxf(fabsf(v[k].x), fabsf(v[k].y)), fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
+                const bool sane = (v[k].x == v[k].x) && (v[k].y == v[k].y) && (v[k].z == v[k].z) && (v[k].w == v[k].w) && a <= 1e30f;
+                sp = sane ? fmaxf(sp, fmaxf(d1, fmaxf(d2, d3))) : inf;
             }
         }
 #pragma unroll
@@ -2197,20 +2284,24 @@ __global__ __launch_bounds__(kBlock) void k_chunk_bounds(const float4 *__restric
                 hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
             }
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sp = fmaxf(sp, __shfl_xor(sp, off, 64));
         if (lane == 0) {
             float *b = bounds + 6 * c;
             b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2];
             b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
+            // (one rounding per difference: a relative 2^-23 up covers it; the test's slack adds more)
+            if (spread) spread[c] = sp * 1.000001f;
         }
     }
 }
 
-void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds) {
+void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds, float *spread) {
     uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) return;
     uint64_t blocks = ((n4 + 63) / 64 + 3) / 4;
     hipLaunchKernelGGL(k_chunk_bounds, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kBlock), 0, s,
-                       (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, bounds);
+                       (const float4 *)c.x, (const float4 *)c.y, (const float4 *)c.z, n4, bounds, spread);
 }
 
 
@@ -2256,7 +2347,8 @@ __global__ __launch_bounds__(kBlock) void k_pack_measure(const uint4 *__restrict
 }
 // exclusive scan of the chunks' plane counts -> hdr[2 c + 1]; one workgroup (a one-off at upload: ~1 ms per 1e8 points)
 __global__ __launch_bounds__(512) void k_pack_scan(const uint32_t *__restrict__ chunk_planes, uint64_t nchunks,
-                                                   uint4 *__restrict__ hdr, uint64_t *__restrict__ total_planes) {
+                                                   uint4 *__restrict__ hdr, uint64_t *__restrict__ total_planes,
+                                                   const float *__restrict__ spread) {
     __shared__ uint32_t s_w[8];
     uint64_t carry = 0;
     for (uint64_t c0 = 0; c0 < nchunks; c0 += 512) {
@@ -2266,7 +2358,8 @@ __global__ __launch_bounds__(512) void k_pack_scan(const uint32_t *__restrict__ 
         const uint32_t incl = block_scan(v, s_w, tot);
         if (c < nchunks) {
             const uint64_t off = carry + (incl - v);
-            hdr[2 * c + 1] = make_uint4((uint32_t)off, (uint32_t)(off >> 32), 0u, 0u);
+            // (.z: the chunk's lane spread, +inf -- no lane test -- when it was not measured)
+            hdr[2 * c + 1] = make_uint4((uint32_t)off, (uint32_t)(off >> 32), spread ? __float_as_uint(spread[c]) : 0x7F800000u, 0u);
         }
         carry += tot;
     }
@@ -2347,7 +2440,7 @@ void pack_measure(hipStream_t s, const Cloud &c, uint4 *hdr, uint32_t *chunk_pla
     if (n4 == 0) return;
     hipLaunchKernelGGL(k_pack_measure, dim3(pack_grid(n4)), dim3(kBlock), 0, s, (const uint4 *)c.x, (const uint4 *)c.y,
                        (const uint4 *)c.z, n4, hdr, chunk_planes);
-    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(512), 0, s, chunk_planes, (n4 + 63) / 64, hdr, total_planes);
+    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(512), 0, s, chunk_planes, (n4 + 63) / 64, hdr, total_planes, c.spread);
 }
 void pack_write(hipStream_t s, const Cloud &c, const uint4 *hdr, uint32_t *planes) {
     const uint64_t n4 = (c.n + 3) / 4;

@@ -147,8 +147,9 @@ __global__ __launch_bounds__(256) void k_order_quality(const float *__restrict__
 }  // namespace
 
 // mean chunk diagonal / cloud diagonal (0 when undefined); returns a hipError_t as int
-int order_quality(hipStream_t s, const float *bounds, uint64_t n, float *ratio) {
+int order_quality(hipStream_t s, const float *bounds, uint64_t n, float *ratio, float absmax[3]) {
     *ratio = 0.f;
+    absmax[0] = absmax[1] = absmax[2] = __builtin_inff();
     const uint64_t nchunks = ((n + 3) / 4 + 63) / 64;
     if (nchunks == 0) return 0;
     struct Out { float sum; uint32_t finite; uint32_t bb[6]; } h, *d = nullptr;
@@ -167,8 +168,10 @@ int order_quality(hipStream_t s, const float *bounds, uint64_t n, float *ratio) 
     if (h.finite == 0 || !(h.bb[0] <= h.bb[3])) return 0;
     float ext2 = 0.f;
     for (int k = 0; k < 3; ++k) {
-        const float ext = ord2f(h.bb[3 + k]) - ord2f(h.bb[k]);
+        const float lo = ord2f(h.bb[k]), hi = ord2f(h.bb[3 + k]);
+        const float ext = hi - lo;
         ext2 += ext * ext;
+        absmax[k] = fabsf(lo) > fabsf(hi) ? fabsf(lo) : fabsf(hi);
     }
     const float cloud = sqrtf(ext2);
     if (cloud > 0.f) *ratio = (h.sum / (float)h.finite) / cloud;
