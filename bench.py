@@ -2,7 +2,9 @@
 """bench.py -- Mpoints/s projected + frames/s of the point-cloud -> framebuffer hot path.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under a launcher -- python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ... --
+    or plainly: without WORLD_SIZE in the environment bench.py starts the N rank processes itself, as children of a
+    process that never touches the GPU, and passes rank 0's JSON line and the launcher's exit code through)
 
 A "step" is one frame of BASELINE.json config C3: a 100 M-point synthetic cloud projected
 to 1920x1080 (clear, min-depth pass, accumulate pass, resolve) plus the depth-heuristic
@@ -140,7 +142,7 @@ def moved_bytes_model(stream_bpp, n_local, stats):
     return b
 
 
-def roofline_of(kern_ms, launches, n_local, traffic, every, stream_bpp=12.0, stats=None, limiter=None):
+def roofline_of(kern_ms, launches, n_local, traffic, every, stream_bpp=12.0, stats=None, limiter=None, head=None):
     """`achieved` = the bytes the dominant kernel MOVES per launch / its average launch time; `frac` = that over
     the 8 TB/s HBM peak -- a roofline fraction, never above 1.  The bytes are the PMC traffic of the committed
     profile when it was taken on exactly this workload (`bytes_source` "pmc"), else the model above ("model":
@@ -154,6 +156,7 @@ def roofline_of(kern_ms, launches, n_local, traffic, every, stream_bpp=12.0, sta
     achieved = moved / t / 1e9
     return {"bound": "hbm", "kernel": "min_depth (k_project_bin: stream + append)", "achieved": achieved,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_profile_head": head if traffic else None,
             "bytes_per_launch": moved, "bytes_source": source, "bytes_model": model,
             "avg_launch_ms": kern_ms, "launches_timed": int(launches),
             "resident_stream_bytes_per_point": stream_bpp,
@@ -170,31 +173,49 @@ def roofline_of(kern_ms, launches, n_local, traffic, every, stream_bpp=12.0, sta
 
 
 def measured_traffic(scene, n_local, W, H, with_filter, pack=1):
-    """(HBM bytes per launch of the dominant kernel, what limits it) from the committed PMC profile -- only when
-    that profile was taken on exactly this workload (else null: a constant is not a measurement)."""
+    """(HBM bytes per launch of the dominant kernel, what limits it, the git revision the PMC record was taken at) from
+    the committed PMC profile -- only when that profile was taken on exactly this workload (else null: a constant is not
+    a measurement).  The revision travels into the JSON line (`roofline.traffic_profile_head`) so that a record older
+    than the kernel it prices is visible."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        for rec in json.load(open(tpath)).get("records", []):
+        doc = json.load(open(tpath))
+        for rec in doc.get("records", []):
             if (rec.get("scene"), rec.get("points"), rec.get("width"), rec.get("height"), rec.get("prefilter"),
                     rec.get("pack", 1)) == (scene, n_local, W, H, with_filter, pack) and rec.get("kernel") == "min_depth":
-                return rec.get("bytes_per_launch"), rec.get("limiter")
+                return rec.get("bytes_per_launch"), rec.get("limiter"), rec.get("head", doc.get("head"))
     except Exception:
         pass
-    return None, None
+    return None, None, None
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N rank processes as CHILDREN (torch.distributed.run as a
+    subprocess; this process has not imported torch, let alone touched the GPU, and never replaces itself), wait for
+    them, pass their output through.  Returns the launcher's exit code: non-zero when any rank failed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -320,21 +341,27 @@ def main():
     # parity gate on pose 0 at FULL size: the resident cloud is copied back and projected by the
     # multi-thread oracle on the host (bounded by host memory: 20 B per point); the same host copy
     # then feeds the CPU baseline
-    parity, cpu, rotated_cloud = None, None, None
+    parity, cpu, rotated_cloud, parity_poses = None, None, None, None
     if rank == 0 and world == 1 and not multi and total <= 250_000_000 and not (args.no_parity and args.no_cpu_baseline):
         orc = entry.load_oracle()
         xyzw, rgba = proj.download_points()
         if not args.no_parity:
-            img, depth = proj.project(poses[0], filtered=with_filter)
-            ref = orc.MTProjector(W, H, host_threads()).project(xyzw, rgba, poses[0])
-            rd, ri = ref["depth_bits"], ref["img"]
-            if with_filter:
-                rf = orc.filter(rd, ri)
-                rd, ri = rf["depth"].view(np.uint32), rf["img"]
-                ok_t = np.array_equal(proj.download(pkg._lib.BUF_TENSOR).reshape(5, H, W), rf["tensor"])
-            else:
-                ok_t = True
-            parity = bool(np.array_equal(depth.view(np.uint32), rd) and np.array_equal(img, ri) and ok_t)
+            # three poses spread over the TIMED set (first, middle, last), not only pose 0
+            parity_poses = sorted({args.warmup, args.warmup + args.steps // 2, args.warmup + args.steps - 1})
+            mt = orc.MTProjector(W, H, host_threads())
+            parity = True
+            for kp in parity_poses:
+                img, depth = proj.project(poses[kp], filtered=with_filter)
+                ref = mt.project(xyzw, rgba, poses[kp])
+                rd, ri = ref["depth_bits"], ref["img"]
+                if with_filter:
+                    rf = orc.filter(rd, ri)
+                    rd, ri = rf["depth"].view(np.uint32), rf["img"]
+                    ok_t = np.array_equal(proj.download(pkg._lib.BUF_TENSOR).reshape(5, H, W), rf["tensor"])
+                else:
+                    ok_t = True
+                parity = parity and bool(np.array_equal(depth.view(np.uint32), rd) and np.array_equal(img, ri) and ok_t)
+            del mt
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(orc, pkg, args, xyzw, rgba)
         if not args.no_extra and args.scene == "room_shell" and not args.overlap:
@@ -367,6 +394,7 @@ def main():
                 rd, ri = rf["depth"].view(np.uint32), rf["img"]
             parity = bool(np.array_equal(proj.download(pkg._lib.BUF_DEPTH), rd) and
                           np.array_equal(proj.download(pkg._lib.BUF_IMAGE), ri))
+            parity_poses = [0]
         S.sync()
 
     # N > 1 at any size: "multi-GPU result identical to the 1-GPU result" (SURVEY 8d).  Rank 0 holds
@@ -455,9 +483,10 @@ def main():
                 info["owned_ms_per_step"] = dt3 / steps * 1e3
             if note3:
                 info["owned_note"] = note3
-            if clean3 and dt3 is not None and dt3 < dt_:
-                dt_, timing_ = dt3, timing3
-                info["used"] = "owned"
+            # (never the headline: in this form only ONE rank ends with each frame -- rotating-owner throughput, not
+            # like-for-like with the two forms above, where every rank holds every frame.  --exchange owned asks for it
+            # explicitly, and the line then says so in `value_semantics`.)
+            info["owned_semantics"] = "rotating-owner throughput: frame k is complete on rank k mod N only"
         return dt_, timing_, info
 
     def kernel_table(timing_):
@@ -495,13 +524,13 @@ def main():
         dtf, tf = S.timed_run(renderers, args.steps, args.warmup)
         kf = kernel_table(tf)
         stf = sample_stats(proj, timed_poses, with_filter)
-        trf, limf = measured_traffic(args.scene, n_local, W, H, with_filter, pack=0)
+        trf, limf, headf = measured_traffic(args.scene, n_local, W, H, with_filter, pack=0)
         fp32_soa = {"what": "option pack = 0: the point kernel streams the fp32 SoA coordinates (12 B/pt, the layout "
                             "BASELINE.json's north_star names) instead of their lossless packed form; same poses, "
                             "bit-identical frames",
                     "value": total * args.steps / dtf / 1e6, "unit": "Mpoints/s", "ms_per_step": dtf / args.steps * 1e3,
                     "steps": args.steps,
-                    "roofline": roofline_of(kf["min_depth"], tf["min_depth"][1], n_local, trf, every, 12.0, stf, limf)
+                    "roofline": roofline_of(kf["min_depth"], tf["min_depth"][1], n_local, trf, every, 12.0, stf, limf, headf)
                                 if kf.get("min_depth") else None}
         proj.set_option("pack", 1)
 
@@ -582,6 +611,55 @@ def main():
               "roofline": roofline_of(k2["min_depth"], t2["min_depth"][1], n2, None, every, bpp2,
                                       sample_stats(pc, timed_poses, False)) if k2.get("min_depth") else None}
         pc.close()
+
+    # BASELINE config C1 (N = 1): a 100k-point synthetic .ply -> 640x480 through the NAIVE single-thread host loop
+    # (plumbing): the cloud is written as a binary-LE .ply (float x, y, z + uchar red, green, blue:
+    # the layout cloudreader.cpp:140-170 reads), read back, put through the loader's 0.25 m grid and flattened the way
+    # the reference hands it to ProjectCloud (Octreegrid.h:162-180); the oracle's single-thread projector is timed on
+    # it, and the GPU renders the same arrays (C1 itself names no GPU: its frame is the parity check of the plumbing).
+    c1 = None
+    if not multi and not args.no_extra and not args.no_cpu_baseline:
+        import tempfile
+        orc = entry.load_oracle()
+        F = pkg.formats
+        n1, W1, H1 = 100_000, 640, 480
+        x1, col1 = orc.generate("room_shell", 0xC0FFEE01, 0, n1, n1)
+        with tempfile.TemporaryDirectory() as td:
+            ply = os.path.join(td, "c1.ply")
+            F.write_ply(ply, x1[:, :3], col1[:, :3])
+            g1 = F.compute_grid(*F.read_ply(ply))
+        v1, k1 = g1.vertex_positions(), g1.vertex_colors()
+        poses1 = [pkg.orbit_projection(k, W1, H1) for k in range(64)]
+        orc.project(v1, k1, poses1[0], W1, H1)
+        t1 = time.perf_counter()
+        frames1 = 0
+        while frames1 < 50 and (frames1 < 3 or time.perf_counter() - t1 < 2.0):
+            ref1 = orc.project(v1, k1, poses1[frames1], W1, H1)
+            frames1 += 1
+        dt1 = time.perf_counter() - t1
+        p1 = pkg.Projector(local_rank)
+        p1.set_resolution(W1, H1)
+        p1.upload_points(v1, k1)
+        i1, d1 = p1.project(poses1[frames1 - 1])
+        for k in range(5):
+            p1.render(poses1[k], False)
+        p1.synchronize()
+        t1 = time.perf_counter()
+        for k in range(50):
+            p1.render(poses1[k], False)
+        p1.synchronize()
+        dg1 = time.perf_counter() - t1
+        p1.close()
+        c1 = {"what": "BASELINE C1: %d-point room_shell (seed 0xC0FFEE01) written to a binary .ply, read back, gridded in "
+                      "0.25 m blocks and flattened like the reference's loader -> %dx%d; the oracle's NAIVE single-thread "
+                      "host loop timed, the GPU frame of the same arrays as the check of the plumbing" % (n1, W1, H1),
+              "cpu_naive": {"value": n1 * frames1 / dt1 / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "port",
+                            "ms_per_frame": dt1 / frames1 * 1e3, "frames": frames1},
+              "gpu": {"value": n1 * 50 / dg1 / 1e6, "unit": "Mpoints/s", "ms_per_step": dg1 / 50 * 1e3, "steps": 50},
+              "blocks": int(len(g1.keys)),
+              "parity_vs_oracle": bool(np.array_equal(d1.view(np.uint32), ref1["depth_bits"]) and
+                                       np.array_equal(i1, ref1["img"]))}
+        del x1, col1, v1, k1, g1
 
     # Reported separately (never part of `value`), N = 1 only.
     extra_cull, ubox, pipelined, rotated = None, None, None, None
@@ -674,15 +752,15 @@ def main():
                 dtu, tu = U.timed_run(U.renderers("allreduce"), m, args.warmup)
                 ku = kernel_table(tu)
                 stu = sample_stats(U.projs[0], timed_poses, with_filter)
-                tru, limu = measured_traffic("uniform_box" if policy == 0 else "uniform_box_sorted", args.points, W, H,
-                                             with_filter)
+                tru, limu, headu = measured_traffic("uniform_box" if policy == 0 else "uniform_box_sorted", args.points, W, H,
+                                                    with_filter)
                 req, two = frame_bytes(args.points, W, H, with_filter)
                 ubox[key] = {"value": args.points * m / dtu / 1e6, "unit": "Mpoints/s", "ms_per_step": dtu / m * 1e3,
                              "steps": m, "reordered_by_library": bool(U.projs[0].get_option("reordered")),
                              "order_ratio": U.projs[0].get_option("order_ratio_ppm") / 1e6,
                              "roofline": roofline_of(ku["min_depth"], tu["min_depth"][1], args.points, tru, every,
                                                      U.projs[0].get_option("packed_millibytes_per_point") / 1000.0, stu,
-                                                     limu),
+                                                     limu, headu),
                              "frame_required_bytes_frac": req / (dtu / m) / 1e9 / HBM_PEAK_GBS}
                 if t_up is not None:
                     ubox[key]["generate_plus_sort_s"] = t_up
@@ -709,6 +787,7 @@ def main():
         dom = max(("min_depth", "accumulate"), key=lambda k: kern.get(k, 0.0))
         required, two_pass = frame_bytes(n_local, W, H, with_filter)
         step_s = dt / args.steps
+        main_traffic = measured_traffic(args.scene, n_local, W, H, with_filter, pack=1 if stream_bpp < 11.9 else 0)
         out = {
             "metric": "Mpoints/sec projected + frames/sec at %dx%d" % (W, H),
             "value": total * args.steps / dt / 1e6,
@@ -740,12 +819,8 @@ def main():
                                         "flight" % (world, "RCCL" if args.backend == "nccl" else "gloo", colour,
                                                     depth_k))) if multi else
                        ("single GPU" + (", %d frames in flight" % depth_k if depth_k > 1 else ""))},
-            "roofline": roofline_of(kern[dom], timing[dom][1], n_local,
-                                    *measured_traffic(args.scene, n_local, W, H, with_filter,
-                                                      pack=1 if stream_bpp < 11.9 else 0)[:1], every, stream_bpp,
-                                    main_stats if dom == "min_depth" else None,
-                                    measured_traffic(args.scene, n_local, W, H, with_filter,
-                                                     pack=1 if stream_bpp < 11.9 else 0)[1])
+            "roofline": roofline_of(kern[dom], timing[dom][1], n_local, main_traffic[0], every, stream_bpp,
+                                    main_stats if dom == "min_depth" else None, main_traffic[1], main_traffic[2])
                         if kern.get(dom) else None,
             # the frame against the bytes THIS design has to move (cloud streamed once: 12 B/pt, 39 B/px of
             # clear / resolve work, ~50 B/px of prefilter) ...
@@ -759,7 +834,9 @@ def main():
             "vs_two_pass_bytes": two_pass / step_s / 1e9 / HBM_PEAK_GBS,
             "kernel_ms": kern,
             "parity_vs_oracle": parity,
+            "parity_poses": parity_poses,
             "parity_vs_single_gpu": parity_single,
+            "c1": c1,
             "fp32_soa": fp32_soa,
             "c2": c2,
             "host_outputs": host_out,
@@ -775,6 +852,8 @@ def main():
                                      "processes on ONE GPU)")
         if exchange_info is not None:
             out["exchange"] = exchange_info
+            if exchange_info.get("used") == "owned":
+                out["value_semantics"] = "rotating-owner throughput: frame k is complete on rank k mod N only"
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

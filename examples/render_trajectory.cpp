@@ -8,6 +8,9 @@
 // pieces the reference takes from those libraries are restated here:
 //   * binary little-endian PLY with float x,y,z + uchar red,green,blue, colours stored B,G,R
 //     (cloudreader.cpp:122-177)
+//   * the loader's grid cache `pcd.oct` (OctreeGrid::readOctreeBinary, Octreegrid.h:83-114; what
+//     CloudReader::loadCloud reads instead of the cloud when ~/.pcl_cache holds one, cloudreader.cpp:182-190):
+//     a <pcl_path> ending in .oct is read as such, blocks and their order kept
 //   * calibration: COLMAP cameras.txt (OPENCV model, floats) or the 6-line txt
 //     (CameraCalibration.cpp:101-209)
 //   * trajectory: COLMAP images.txt (README.md:92, world->camera) when the file is named
@@ -140,6 +143,34 @@ bool load_ply(const std::string& file, std::map<int, Block>& grid) {
     return true;
 }
 
+// OctreeGrid::readOctreeBinary (Octreegrid.h:83-114): numBlocksX/Y/Z and the block count as four ints, then per block
+// its key (int), the point count (size_t), n x 3 floats, n x 3 colour bytes (as stored: B,G,R) and the block's
+// bbMin / bbMax (3 floats each; the projector never reads them).  Blocks keep the file's order.
+bool load_oct(const std::string& file, std::map<int, Block>& grid, size_t& points) {
+    std::ifstream ss(file, std::ios::binary);
+    if (!ss) { std::cerr << "Failed to open file: " << file << "\n"; return false; }
+    int dims[4];
+    ss.read(reinterpret_cast<char*>(dims), sizeof dims);
+    if (!ss || dims[3] < 0) return false;
+    points = 0;
+    for (int b = 0; b < dims[3]; ++b) {
+        int key; unsigned long long n;
+        ss.read(reinterpret_cast<char*>(&key), 4);
+        ss.read(reinterpret_cast<char*>(&n), 8);
+        if (!ss || n > (1ull << 32)) return false;
+        Block& blk = grid[key];  // (a std::map: key order; the frame does not depend on the point order)
+        const size_t at = blk.positions.size();
+        blk.positions.resize(at + n); blk.colors.resize(at + n);
+        ss.read(reinterpret_cast<char*>(blk.positions.data() + at), (std::streamsize)(n * 12));
+        ss.read(reinterpret_cast<char*>(blk.colors.data() + at), (std::streamsize)(n * 3));
+        float bb[6];
+        ss.read(reinterpret_cast<char*>(bb), sizeof bb);
+        if (!ss) return false;
+        points += n;
+    }
+    return true;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -158,8 +189,14 @@ int main(int argc, char** argv) {
     Calibration calibration;
     if (!load_calibration(argv[3], calibration)) return -1;
     std::map<int, Block> grid;
-    if (!load_ply(argv[1], grid)) return -1;
-    std::cout << "Loaded " << grid[0].positions.size() << " points" << std::endl;  // main.cpp:86
+    size_t points = 0;
+    if (ends_with(argv[1], ".oct")) {
+        if (!load_oct(argv[1], grid, points)) return -1;
+    } else {
+        if (!load_ply(argv[1], grid)) return -1;
+        points = grid[0].positions.size();
+    }
+    std::cout << "Loaded " << points << " points" << std::endl;  // main.cpp:86
     std::vector<M44> trajectory = load_trajectory(argv[2]);
     const int W = calibration.getWidth(), H = calibration.getHeight();
     try {

@@ -31,7 +31,11 @@
 extern "C" {
 #endif
 
-#define RTR_ABI_VERSION 1
+/* Bumped whenever a struct a caller allocates changes size or an entry point changes meaning (2: rtr_p2p_handles grew
+ * from 6 to 9 handle blocks, RTR_ERR_INTERNAL, the asynchronous outputs).  A binding compares rtr_abi_version() -- what
+ * the loaded library was built with -- against the RTR_ABI_VERSION it was compiled with and refuses to go on when they
+ * differ (the Python mirror and rtr::ProjectCloud do). */
+#define RTR_ABI_VERSION 2
 #define RTR_EMPTY_DEPTH 0x7F7FFFFFu /* render.cu:166, project_cloud.cu:316: bits of FLT_MAX */
 
 typedef struct rtr_ctx rtr_ctx;
@@ -94,6 +98,17 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *  "cull": 1 = skip 256-point chunks whose bounding box is provably outside the frustum
  *          (exact: same frame; an algorithmic byte reduction, off by default and reported
  *          separately from the roofline figure; needs a spatially coherent point order).
+ *  "lean": 1 (default) = a whole single-GPU frame (rtr_render and the calls built on it) whose point kernel needs no
+ *          epilogue -- no tile above "split_threshold" seen lately, option "overlap" off, no peer-to-peer exchange open
+ *          -- ends that kernel without last-workgroup detection and bookkeeping pass: the tile kernel's workgroups read
+ *          and reset their stream counters themselves, one extra workgroup does the frame's bookkeeping off the
+ *          critical path (5-6 us per frame).  0 = always the epilogue.  After a lean frame rtr_accumulate_pass
+ *          re-projects the cloud (the bins were consumed).
+ *  "lane_test": 1 (default) = the tile-binned point kernel first decodes and projects ONE point per lane (of
+ *          the four consecutive points a lane holds) and bounds the other three by the chunk's "lane spread"
+ *          (the largest coordinate difference inside a lane, measured once per upload): a 256-point chunk with
+ *          no lane near the frustum is neither decoded nor projected in full.  Every point still goes through
+ *          the exact arithmetic before it can reach a pixel; 0 = every point of every chunk, as before.
  *  "pack": the tile-binned point kernel reads the coordinates from a LOSSLESS packed form, built once after
  *          every upload / generation / sort (and at once for the resident cloud when the option is set): per
  *          256-point chunk and axis the fp32 bit patterns are base + delta with 0..4 delta bytes, i.e. 6-9
@@ -123,14 +138,17 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          on an ordinary view).  Default -1 = automatic: 1 (8 bytes) on ordinary frames, 4 (64 bytes) while frames
  *          with tiles above "split_threshold" have been seen lately (and in the phase / sharded calls).
  *  "p2p_timeout_ms": how long a flag barrier of the peer-to-peer exchange (section 5b) waits for a rank
- *          that does not arrive before it flags the frame in rtr_p2p_status (default 2000).
+ *          that does not arrive before it flags the frame in rtr_p2p_status (default 2000).  rtr_get_option("p2p_open")
+ *          reads 1 while the peers' buffers are mapped: a new cloud (rtr_upload_points, rtr_generate_synthetic with
+ *          another point count) or resolution closes the exchange on this rank -- every rank must then export /
+ *          open again, together.  The exchange and option "overlap" exclude each other.
  *  "debug_dyn_cap": test aid -- caps the pool of dynamic stream extents at this many entries (-1 = off), so that a
  *          heavy tile overflows it and the error path (RTR_ERR_INTERNAL) can be exercised.
  *  "xp": only in RTR_EXPERIMENT builds (make experiment): switches parts of the point kernel off for
  *          timing attribution -- frames are WRONG while it is non-zero; the shipped library rejects it.
  *  "probe_variant": measurement aid of tools/probe_variants.py (selects the rtr_stream_probe kernel). */
 int rtr_set_option(rtr_ctx *ctx, const char *key, int value);
-/* Reads an option back; also "reordered" (1: the resident cloud was sorted by the library),
+/* Reads an option back; also "p2p_open" (see "p2p_timeout_ms"), "reordered" (1: the resident cloud was sorted by the library),
  * "order_ratio_ppm" (mean chunk-box diagonal / cloud diagonal as uploaded, in millionths), "packed" and
  * "packed_millibytes_per_point" (see "pack"). */
 int rtr_get_option(rtr_ctx *ctx, const char *key, int *value);
@@ -254,7 +272,13 @@ int rtr_p2p_render(rtr_ctx *ctx, const float P[16], int with_filter);
  * frame.  Afterwards only rank `frame_owner` holds the GLOBAL frame (RTR_BUF_DEPTH / IMAGE and the prefilter's outputs:
  * it collects the other ranks' tiles); the buffers of the other ranks hold their own tiles only.  All ranks must pass
  * the same frame_owner; rotating it (frame k -> rank k mod world) spreads the collect + prefilter over the ranks, e.g.
- * one U-Net consumer per GPU.  Tiles are not split over workgroups in this form (split_threshold is ignored). */
+ * one U-Net consumer per GPU.  Tiles are not split over workgroups in this form (split_threshold is ignored).
+ * PRECONDITION on the ranks that are NOT the frame's owner: the call returns (its work queued) right after the second
+ * barrier, while the owner is still reading this rank's RTR_BUF_DEPTH and image exchange copy over the mappings.  Only
+ * the next rtr_p2p_render_owned's first barrier orders those reads against new writes: between two owned frames a
+ * non-owner must not queue anything else that writes the frame buffers (rtr_render, rtr_clear, the phase calls,
+ * rtr_p2p_render) without a barrier of the caller's own across the ranks (the Python ShardedProjector and bench.py
+ * put a torch.distributed barrier / all-reduce there). */
 int rtr_p2p_render_owned(rtr_ctx *ctx, const float P[16], int with_filter, int frame_owner);
 int rtr_p2p_status(rtr_ctx *ctx, uint32_t *barrier_timeouts);
 
@@ -293,8 +317,11 @@ int rtr_stream_probe(rtr_ctx *ctx, const float P[16]);
 int rtr_timing_enable(rtr_ctx *ctx, int on);
 /* Statistics of the last binned frame (mode 1; synchronises the stream): out[0] work items of the
  * tile kernel, [1] of them slices of split tiles, [2] in-frustum entries, [3] entries of the
- * heaviest tile, [4] slice size used, [5] tile-store error bits of THAT frame (0 = none; 1 = an extent never
- * appeared, 2 = the extent pool overflowed: entries were dropped), [6] split tiles, [7] 256-point chunks with
+ * heaviest tile, [4] slice size used, [5] tile-store error bits of THAT frame's point kernel (0 = none; 1 = an extent
+ * never appeared, 2 = the extent pool overflowed: entries were dropped; the tile kernels' own bits -- 4 = a contested
+ * tile of an owner-computes sharded frame had more stream pieces than its table holds, 8 = the split tiles' second
+ * phase gave up waiting for the first -- go straight to the word every synchronising call checks and surface there
+ * as RTR_ERR_INTERNAL), [6] split tiles, [7] 256-point chunks with
  * at least one in-frustum point (each loads 1 KiB of colours). */
 int rtr_frame_stats(rtr_ctx *ctx, uint32_t out[8]);
 int rtr_timing_reset(rtr_ctx *ctx);

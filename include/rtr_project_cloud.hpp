@@ -54,6 +54,9 @@ public:
                 rgba.push_back(c[0]); rgba.push_back(c[1]); rgba.push_back(c[2]); rgba.push_back(255);
             }
         }
+        if (rtr_abi_version() != RTR_ABI_VERSION)  // (a library built from another rtr.h: struct sizes may differ)
+            throw std::runtime_error("librtr_hip.so has ABI version " + std::to_string(rtr_abi_version()) +
+                                     ", this header is version " + std::to_string(RTR_ABI_VERSION));
         check(nullptr, rtr_create(&ctx_, device));
         // (the library's default upload policy: the point order is measured and the cloud Morton-sorted once when its
         // 256-point chunks are not compact -- the grid's 0.25 m blocks are unordered inside -- then packed losslessly)

@@ -48,6 +48,8 @@ def lib():
         L.orc_generate.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         L.orc_filter.restype = C.c_int
         L.orc_project_mt.restype = C.c_int
+        L.orc_envelope_points.restype = C.c_int
+        L.orc_project_variant.restype = C.c_int
         _lib = L
         assert L.orc_selftest() == 1, "oracle build violates the arithmetic contract"
     return _lib
@@ -170,6 +172,40 @@ class MTProjector:
         assert rc == 0
         return {"depth_bits": self.depth.reshape(self.H, self.W), "acc": self.acc.reshape(self.H, self.W, 4),
                 "img": self.img.reshape(self.H, self.W, 3)}
+
+
+MM_VARIANTS = {0: "contract (right products fused, left to right)", 1: "first add fused with the left product",
+               2: "nothing contracted (-fmad=false)", 3: "re-associated: all fused, right to left",
+               4: "re-associated: m3 folded into the first fma"}
+DV_VARIANTS = {0: "contract: x * RN(1/z)", 1: "IEEE x / z", 2: "x * (RN(1/z) - 2 ulp)", 3: "x * (RN(1/z) - 1 ulp)",
+               4: "x * (RN(1/z) + 1 ulp)", 5: "x * (RN(1/z) + 2 ulp)"}
+
+
+def envelope_points(xyz, P, W, H, mm, dv, nthreads=8):
+    """Per-point comparison of arithmetic variant (mm, dv) with the contract (rtr_oracle.c, "ENVELOPE").
+    -> dict(accepted, either, flips, max_depth_ulp)"""
+    xyz, _ = _cloud(xyz, None)
+    P = _P(P)
+    out = np.zeros(4, np.uint64)
+    rc = lib().orc_envelope_points(_ptr(xyz), C.c_size_t(xyz.strides[0]), C.c_size_t(xyz.shape[0]), _ptr(P), W, H,
+                                   int(mm), int(dv), int(nthreads), _ptr(out))
+    assert rc == 0
+    return {"accepted": int(out[0]), "either": int(out[1]), "flips": int(out[2]), "max_depth_ulp": int(out[3])}
+
+
+def project_variant(xyz, rgb, P, W, H, mm, dv, params=None):
+    """A whole frame under arithmetic variant (mm, dv): same outputs as project()."""
+    xyz, rgb = _cloud(xyz, rgb)
+    P = _P(P)
+    prm = params or default_params()
+    depth = np.empty(W * H, np.uint32)
+    acc = np.empty(W * H * 4, np.uint32)
+    img = np.empty(W * H * 3, np.uint8)
+    rc = lib().orc_project_variant(_ptr(xyz), C.c_size_t(xyz.strides[0]), _ptr(rgb), C.c_size_t(rgb.strides[0]),
+                                   C.c_size_t(xyz.shape[0]), _ptr(P), W, H, C.byref(prm), int(mm), int(dv),
+                                   _ptr(depth), _ptr(acc), _ptr(img))
+    assert rc == 0
+    return {"depth_bits": depth.reshape(H, W), "acc": acc.reshape(H, W, 4), "img": img.reshape(H, W, 3)}
 
 
 def filter(depth_bits, img, params=None, want_tensor=True):

@@ -311,6 +311,120 @@ int orc_project_mt(const void *xyz, size_t xyz_stride, const uint8_t *rgb, size_
 }
 
 /* ------------------------------------------------------------------------ */
+/* ENVELOPE of the unpinned arithmetic (tests/test_oracle_envelope.py, tools/oracle_envelope.py).
+ * The reference's projection is not reproducible off an NVIDIA toolchain in two places:
+ *   render.cu:33-40  matmul: `m[0]*v.x + m[1]*v.y + m[2]*v.z + m[3]` under nvcc's default -fmad=true -- which of
+ *                    the products are contracted into the following add is the compiler's choice;
+ *   render.cu:65-66  __fdividef(r.x, r.z): x times an APPROXIMATE reciprocal (<= 2 ulp by the CUDA documentation).
+ * The variants below are the evaluations a CUDA build could plausibly produce; they exist only to MEASURE how far
+ * the contract (mm = 0, dv = 0) can be from them -- nothing in the product or in the parity tests uses them.
+ *   mm 0  contract: t = m0 x; t = fma(m1, y, t); t = fma(m2, z, t); r = t + m3        (left to right, right products fused)
+ *   mm 1  the first add fused with the LEFT product: t = m1 y; t = fma(m0, x, t); t = fma(m2, z, t); r = t + m3
+ *   mm 2  nothing contracted (-fmad=false): ((m0 x + m1 y) + m2 z) + m3
+ *   mm 3  re-associated, all fused right to left: fma(m0, x, fma(m1, y, fma(m2, z, m3)))
+ *   mm 4  re-associated, m3 folded into the first fma: fma(m2, z, fma(m1, y, fma(m0, x, m3)))
+ *   dv 0  contract: x * RN(1 / z)      dv 1  IEEE x / z      dv 2..5  x * (RN(1 / z) -2, -1, +1, +2 ulp)            */
+static inline float row_v(const float *m, float x, float y, float z, int mm) {
+    switch (mm) {
+    case 1: return f_add(fmaf(m[2], z, fmaf(m[0], x, f_mul(m[1], y))), m[3]);
+    case 2: return f_add(f_add(f_add(f_mul(m[0], x), f_mul(m[1], y)), f_mul(m[2], z)), m[3]);
+    case 3: return fmaf(m[0], x, fmaf(m[1], y, fmaf(m[2], z, m[3])));
+    case 4: return fmaf(m[2], z, fmaf(m[1], y, fmaf(m[0], x, m[3])));
+    default: return f_add(fmaf(m[2], z, fmaf(m[1], y, f_mul(m[0], x))), m[3]);
+    }
+}
+static inline float quot_v(float a, float rz, int dv) {
+    if (dv == 1) return f_div(a, rz);
+    float inv = f_div(1.0f, rz);
+    if (dv >= 2) {
+        static const int k[4] = {-2, -1, 1, 2};
+        uint32_t b = f2u(inv);
+        if (b > 0x00800002u && b < 0x7F7FFFFDu) inv = u2f(b + (uint32_t)k[dv - 2]); /* positive normal: +- k ulp */
+    }
+    return f_mul(a, inv);
+}
+static inline int project_point_v(const float *P, float x, float y, float z, int W, int H, int mm, int dv,
+                                  uint32_t *pix, float *depth) {
+    float rx = row_v(P, x, y, z, mm), ry = row_v(P + 4, x, y, z, mm), rz = row_v(P + 8, x, y, z, mm);
+    if (!(rz > 0.0f)) return 0;
+    float fu = rintf(quot_v(rx, rz, dv)), fv = rintf(quot_v(ry, rz, dv));
+    if (!(fu >= 0.0f && fu < (float)W && fv >= 0.0f && fv < (float)H)) return 0;
+    *pix = (uint32_t)((int)fv * W + (int)fu);
+    *depth = rz;
+    return 1;
+}
+/* Per-point comparison of a variant with the contract over one slice of a cloud.
+ * out[0] points the contract accepts, out[1] points either accepts, out[2] points whose acceptance or pixel differs,
+ * out[3] largest |depth bits difference| (ulp) among the points both accept.                                         */
+typedef struct { const void *xyz; size_t xs, lo, hi; const float *P; int W, H, mm, dv; uint64_t out[4]; } env_job;
+static void *env_worker(void *arg) {
+    env_job *j = (env_job *)arg;
+    uint64_t acc0 = 0, either = 0, flips = 0, ulp = 0;
+    for (size_t i = j->lo; i < j->hi; ++i) {
+        const float *p = xyz_at(j->xyz, j->xs, i);
+        uint32_t pa = 0, pb = 0; float da = 0.f, db = 0.f;
+        const int a = project_point(j->P, p[0], p[1], p[2], j->W, j->H, &pa, &da);
+        const int b = project_point_v(j->P, p[0], p[1], p[2], j->W, j->H, j->mm, j->dv, &pb, &db);
+        acc0 += (uint64_t)a;
+        either += (uint64_t)(a | b);
+        if (a != b || (a && pa != pb)) flips += 1;
+        if (a && b) {
+            const uint32_t ua = f2u(da), ub = f2u(db);
+            const uint64_t d = ua > ub ? ua - ub : ub - ua;
+            if (d > ulp) ulp = d;
+        }
+    }
+    j->out[0] = acc0; j->out[1] = either; j->out[2] = flips; j->out[3] = ulp;
+    return NULL;
+}
+int orc_envelope_points(const void *xyz, size_t xyz_stride, size_t n, const float P[16], int W, int H, int mm, int dv,
+                        int nthreads, uint64_t out[4]) {
+    if (nthreads < 1 || mm < 0 || mm > 4 || dv < 0 || dv > 5) return -1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    env_job *jobs = (env_job *)malloc(sizeof(env_job) * nthreads);
+    for (int t = 0; t < nthreads; ++t) {
+        jobs[t] = (env_job){xyz, xyz_stride, n * t / nthreads, n * (t + 1) / nthreads, P, W, H, mm, dv, {0, 0, 0, 0}};
+        pthread_create(&th[t], NULL, env_worker, &jobs[t]);
+    }
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        pthread_join(th[t], NULL);
+        out[0] += jobs[t].out[0]; out[1] += jobs[t].out[1]; out[2] += jobs[t].out[2];
+        if (jobs[t].out[3] > out[3]) out[3] = jobs[t].out[3];
+    }
+    free(th); free(jobs);
+    return 0;
+}
+/* A whole frame (A1..A6, single thread) under a variant: what the frame buffers of such a build would hold.           */
+int orc_project_variant(const void *xyz, size_t xyz_stride, const uint8_t *rgb, size_t rgb_stride, size_t n,
+                        const float P[16], int W, int H, const orc_params *prm, int mm, int dv,
+                        uint32_t *depth, uint32_t *acc, uint8_t *img) {
+    if (mm < 0 || mm > 4 || dv < 0 || dv > 5) return -1;
+    const size_t npix = (size_t)W * H;
+    orc_clear(depth, acc, npix);
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = xyz_at(xyz, xyz_stride, i);
+        uint32_t pix; float d;
+        if (!project_point_v(P, p[0], p[1], p[2], W, H, mm, dv, &pix, &d)) continue;
+        const uint32_t b = f2u(d);
+        if (b < depth[pix]) depth[pix] = b;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = xyz_at(xyz, xyz_stride, i);
+        uint32_t pix; float d;
+        if (!project_point_v(P, p[0], p[1], p[2], W, H, mm, dv, &pix, &d)) continue;
+        if (d > f_add(u2f(depth[pix]), prm->depth_window)) continue;
+        const uint8_t *c = rgb + i * rgb_stride;
+        acc[4 * (size_t)pix + 0] += c[0];
+        acc[4 * (size_t)pix + 1] += c[1];
+        acc[4 * (size_t)pix + 2] += c[2];
+        acc[4 * (size_t)pix + 3] += 1u;
+    }
+    if (img) orc_resolve(acc, npix, img);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* depth-heuristic prefilter                                                  */
 
 /* A8 reduce (project_cloud.cu:28-53): 2x2 min-pool, source row stride 2*w */

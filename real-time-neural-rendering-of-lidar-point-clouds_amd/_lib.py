@@ -53,6 +53,7 @@ def build(force=False):
     return LIB_PATH
 
 
+ABI_VERSION = 2  # include/rtr.h RTR_ABI_VERSION
 _lib = None
 
 
@@ -66,6 +67,9 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, u64, sz, i32 = C.c_void_p, C.c_uint64, C.c_size_t, C.c_int
     L.rtr_abi_version.restype = i32
+    if L.rtr_abi_version() != ABI_VERSION:  # caller-allocated structs (P2P_HANDLES_BYTES) would be mis-sized
+        raise OSError("%s has ABI version %d, this binding was written for %d: rebuild (`python __graft_entry__.py`)"
+                      % (LIB_PATH, L.rtr_abi_version(), ABI_VERSION))
     L.rtr_device_count.argtypes = []
     L.rtr_create.argtypes = [C.POINTER(vp), i32]
     L.rtr_destroy.argtypes = [vp]

@@ -34,6 +34,9 @@ struct rtr_ctx {
     float *spread = nullptr;    // lane spread per 256-point chunk (rtr::Cloud::spread: T1's lane test)
     float absmax[3] = {0.f, 0.f, 0.f};  // largest finite |x|, |y|, |z| of the resident cloud
     int opt_lane_test = 1;      // T1 tests one point per lane first (option "lane_test")
+    int opt_lean = 1;           // whole single-GPU frames without split tiles end T1 without its epilogue (option "lean")
+    bool last_lean = false;     // the last binned frame was a lean one (its statistics are folded on demand) ...
+    int lean_parity = 0;        // ... and this was its parity
     uint64_t n = 0, cap = 0;
     uint4 *pk_hdr = nullptr;        // rtr::PackedXyz of the resident cloud (option "pack"); null: not in use
     uint32_t *pk_planes = nullptr;
@@ -293,6 +296,8 @@ int ensure_tiles(rtr_ctx *c, hipStream_t s) {
             std::vector<uint32_t> ident((size_t)nt);
             for (int i = 0; i < nt; ++i) ident[(size_t)i] = (uint32_t)i;
             HIP_TRY(c, hipMemcpyAsync(rtr::ts_perm(t), ident.data(), (size_t)nt * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipMemcpyAsync(rtr::ts_order(t, 0), ident.data(), (size_t)nt * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipMemcpyAsync(rtr::ts_order(t, 1), ident.data(), (size_t)nt * 4, hipMemcpyHostToDevice, s));
             HIP_TRY(c, hipStreamSynchronize(s));  // `ident` goes out of scope
         }
     }
@@ -319,7 +324,9 @@ int ensure_tiles(rtr_ctx *c, hipStream_t s) {
 int ensure_lists(rtr_ctx *c) {
     auto &f = c->F();
     if (f.dyn && f.pool_n == c->n) return RTR_OK;
-    if (c->p2p.open || c->p2p.red) p2p_release(c);  // (the peers map this pool: export / open again after a new cloud)
+    // (the peers map the pool that was EXPORTED -- set 0's: export / open again after a new cloud.  The second set's
+    // pool, first allocated by a frame with option "overlap", is nobody else's business)
+    if (&f == &c->fs[0] && (c->p2p.open || c->p2p.red)) p2p_release(c);
     dfree(f.dyn);
     c->list_valid = false;
     f.dyn_cap = 2 * c->n + 64;
@@ -401,9 +408,11 @@ int check_store_error(rtr_ctx *c) {
     if (!c->err_host) return RTR_OK;
     const uint32_t e = __atomic_exchange_n(c->err_host, 0u, __ATOMIC_ACQUIRE);
     if (e == 0u) return RTR_OK;
-    return fail(c, RTR_ERR_INTERNAL, "tile store error 0x%x: %s%s-- entries were dropped, frames rendered since the last "
+    return fail(c, RTR_ERR_INTERNAL, "tile store error 0x%x: %s%s%s%s-- entries were dropped, frames rendered since the last "
                 "synchronising call are incomplete", e, (e & 1u) ? "a stream extent never appeared " : "",
-                (e & 2u) ? "the dynamic extent pool overflowed " : "");
+                (e & 2u) ? "the dynamic extent pool overflowed " : "",
+                (e & 4u) ? "a contested tile of a sharded frame had more stream pieces than its table holds " : "",
+                (e & 8u) ? "the split tiles' second phase gave up waiting for the first " : "");
 }
 
 // after the last reader of the active list / bin set has been queued on the tail stream
@@ -589,6 +598,8 @@ static int set_overlap(rtr_ctx *c, bool on) {
         return RTR_OK;
     }
     if (c->opt_overlap) return RTR_OK;
+    // (the peers of a sharded frame read THE exported tile store; alternating between two of them is for single-GPU frames)
+    if (c->p2p.open) return fail(c, RTR_ERR_INVALID, "option overlap cannot be switched on while the peer-to-peer exchange is open (rtr_p2p_close first)");
     int ncu = 0;
     HIP_TRY(c, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
     if (c->opt_tail_cus > 0) {
@@ -696,6 +707,10 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
         c->opt_cull = value != 0;
         return RTR_OK;
     }
+    if (!strcmp(key, "lean")) {  // whole frames without T1's epilogue when nothing needs it (rtr_render)
+        c->opt_lean = value != 0;
+        return RTR_OK;
+    }
     if (!strcmp(key, "lane_test")) {  // T1: one point per lane first (k_project_bin); 0 = every point, as in round 3
         c->opt_lane_test = value != 0;
         c->list_valid = false;
@@ -735,6 +750,8 @@ int rtr_get_option(rtr_ctx *c, const char *key, int *value) {
     else if (!strcmp(key, "order_ratio_ppm")) *value = (int)(c->order_ratio * 1e6f);  // chunk / cloud diagonal as uploaded
     else if (!strcmp(key, "cull")) *value = c->opt_cull;
     else if (!strcmp(key, "lane_test")) *value = c->opt_lane_test;
+    else if (!strcmp(key, "lean")) *value = c->opt_lean;
+    else if (!strcmp(key, "p2p_open")) *value = c->p2p.open ? 1 : 0;  // the peers' buffers are mapped (rtr_p2p_open)
     else if (!strcmp(key, "pack")) *value = c->opt_pack;
     else if (!strcmp(key, "packed")) *value = c->pk_hdr ? 1 : 0;  // the point kernel reads the packed coordinates
     else if (!strcmp(key, "packed_millibytes_per_point"))         // its coordinate stream, headers included (12000 = raw)
@@ -818,7 +835,9 @@ static int pack_cloud(rtr_ctx *c) {
         if (planes) (void)hipFree(planes);
         return RTR_OK;
     };
-    if (hipMalloc((void **)&hdr, nchunks * 2 * sizeof(uint4)) != hipSuccess) return give_up();
+    // (+ one zero header: the point kernel reads headers in pairs)
+    if (hipMalloc((void **)&hdr, (nchunks + 1) * 2 * sizeof(uint4)) != hipSuccess) return give_up();
+    if (hipMemsetAsync(hdr + nchunks * 2, 0, 2 * sizeof(uint4), c->stream) != hipSuccess) return give_up();
     if (hipMalloc(&cnt.p, nchunks * sizeof(uint32_t)) != hipSuccess) return give_up();
     if (hipMalloc(&tot.p, 2 * sizeof(uint64_t)) != hipSuccess) return give_up();
     if (hipMemsetAsync(tot.p, 0, 2 * sizeof(uint64_t), c->stream) != hipSuccess) return give_up();
@@ -1042,8 +1061,10 @@ static bool use_tiles(const rtr_ctx *c) {
 // the tile launches are the frame buffers' only writers: `clear_split`).
 // With `overlapped` T1 goes to the front stream and fills the set the tail is NOT reading, so it
 // runs beside T4 / the prefilter of the previous frame.
-static int bin_points(rtr_ctx *c, const float P[16], bool overlapped, bool clear_split, bool no_split = false) {
+static int bin_points(rtr_ctx *c, const float P[16], bool overlapped, bool clear_split, bool no_split = false,
+                      bool lean = false) {
     c->list_valid = false;
+    c->last_lean = false;
     c->p2p.occ_current = false;
     c->p2p.occ_from_scan = false;
     hipStream_t s1 = c->stream;
@@ -1068,8 +1089,8 @@ static int bin_points(rtr_ctx *c, const float P[16], bool overlapped, bool clear
     {
         Timed tm(c, RTR_K_MIN_DEPTH, s1, true);
         rtr::launch_project_bin(s1, cloud_of(c), make_proj(P), c->W, c->H, t, c->opt_cull ? c->bounds : nullptr,
-                                (clear_split ? 1 : 0) | (no_split ? 2 : 0) | (c->opt_lane_test ? 0 : 4), c->opt_phases, c->opt_xp,
-                                tm.a, tm.b);
+                                (clear_split ? 1 : 0) | (no_split ? 2 : 0) | (c->opt_lane_test ? 0 : 4) | (lean ? 8 : 0),
+                                c->opt_phases, c->opt_xp, tm.a, tm.b);
         c->p2p.occ_from_scan = c->p2p.open;
     }
     if (overlapped) {
@@ -1091,7 +1112,7 @@ int rtr_min_depth_pass(rtr_ctx *c, const float P[16]) {
         if (int rc = bin_points(c, P, false, c->p2p.whole_frame)) return rc;
         Timed t(c, RTR_K_TILE);
         rtr::launch_tile(c->stream, 1, c->W, c->H, c->F().store, c->prm.depth_window, c->depth, c->acc, c->img,
-                         c->p2p.whole_frame ? 6 : 0, nullptr);  // 2: only writer, 4: tiles without entries are not written
+                         (c->p2p.whole_frame ? 6 : 0) | (c->lean_parity << 4), nullptr);  // 2: only writer, 4: tiles without entries are not written
         mark_consumed(c);
     } else {
         Timed t(c, RTR_K_MIN_DEPTH);
@@ -1205,7 +1226,14 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
             split_launch = c->split_cooldown > 0;
             if (c->split_cooldown > 0) --c->split_cooldown;
         }
-        if ((rc = bin_points(c, P, overlapped, !overlapped, !split_launch))) return rc;
+        // LEAN frames (rtr_kernels.h, ts_off_order): no split launch pending, one stream, no peers -- T1 ends without
+        // ticket and epilogue, the tile workgroups read and reset their stream counters themselves
+        const bool lean = c->opt_lean && !overlapped && !split_launch && !c->p2p.open;
+        if ((rc = bin_points(c, P, overlapped, !overlapped, !split_launch, lean))) return rc;
+        if (lean) {
+            c->lean_parity ^= 1;
+            c->last_lean = true;
+        }
         if (overlapped && split_launch) rtr::launch_reset_split(c->stream, c->W, c->H, c->F().store, c->depth, c->acc);
         // with the default four levels the tile kernel also emits the prefilter's pyramid and
         // min / max partials (F1) while the finished depth tile is still in LDS
@@ -1220,7 +1248,8 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
         {
             Timed t(c, RTR_K_TILE);
             rtr::launch_tile(c->stream, 0, c->W, c->H, c->F().store, c->prm.depth_window, c->depth, c->acc, c->img,
-                             c->opt_keep_accum, pyr.enable ? &pyr : nullptr);
+                             c->opt_keep_accum | (lean ? 8 : 0) | (c->lean_parity << 4), pyr.enable ? &pyr : nullptr);
+            if (lean) c->list_valid = false;  // (the tile launch has consumed and reset the stream counters)
             // tiles heavier than option "split_threshold" are split over several workgroups: a second launch takes
             // the minimum over each slice (they meet in the depth buffer), then -- behind a barrier over its 256
             // workgroups -- accumulates the slices against that minimum, and the last slice of each tile resolves it
@@ -1364,6 +1393,7 @@ int rtr_p2p_export(rtr_ctx *c, rtr_p2p_handles *mine) {
     NEED(c, mine != nullptr, "handles is NULL");
     if (int rc = check_frame(c)) return rc;
     static_assert(sizeof(hipIpcMemHandle_t) <= 64, "handle block too small");
+    NEED(c, !c->opt_overlap, "the peer-to-peer exchange needs option overlap off (the peers map ONE tile store)");
     DevGuard g(c->device);
     HIP_TRY(c, sync_streams(c));
     // (the owner-computes form reads the peers' tile stores: allocate this rank's now -- it is sized by the cloud)
@@ -1664,6 +1694,7 @@ int rtr_frame_stats(rtr_ctx *c, uint32_t out[8]) {
     NEED(c, out != nullptr, "out is NULL");
     NEED(c, c->F().store.meta != nullptr, "no binned frame yet");
     DevGuard g(c->device);
+    if (c->last_lean) rtr::launch_lean_fold(c->stream, c->W, c->H, c->F().store, c->lean_parity);  // (lean frames fold lazily)
     HIP_TRY(c, hipMemcpyAsync(out, rtr::ts_hdr(c->F().store), 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, sync_streams(c));
     return RTR_OK;

@@ -155,7 +155,21 @@ __host__ __device__ constexpr size_t ts_off_cnt4(int nst, int nt) { return ts_al
 //                32 words on lines of their own take 32 adds each, and the last arrival of each adds to ticket[]
 constexpr int kSubTickets = 32;
 __host__ __device__ constexpr size_t ts_off_sub(int nst, int nt) { return ts_off_cnt4(nst, nt) + (size_t)nt * 4; }
-__host__ __device__ constexpr size_t ts_meta_words(int nst, int nt) { return ts_off_sub(nst, nt) + (size_t)kSubTickets * 32; }
+// LEAN frames (whole single-GPU frames without split tiles: the usual case): T1 ends without ticket and epilogue; the
+// tile kernel's workgroup at launch position b takes tile order[b], reads that tile's stream counters ITSELF and resets
+// them; the frame's book-keeping (statistics, error word, pool cursor, next launch order) is done by the tile launch's
+// one extra workgroup, off every critical path.
+// order[2][nt]   launch position -> tile (the inverse of perm[]), per frame parity: the tile workgroups of a lean frame of
+//                parity p read order[p] while that launch's extra workgroup writes order[p ^ 1] for the next frame
+// lcnt[2][nt]    per frame parity: entries per tile of a lean frame, stored by its tile workgroups (plain stores: 2040
+//                adds on a handful of statistics words would queue up on one memory channel and hold every tile
+//                workgroup's first wave back -- measured: +13 us on the tile kernel); summed up into hdr[] by the NEXT lean
+//                frame's extra workgroup (or by rtr_frame_stats), which sees them complete and stable
+// lflag[4]       lflag[p] = 1 while lcnt[p] holds a frame that has not been folded into hdr[] yet
+__host__ __device__ constexpr size_t ts_off_order(int nst, int nt) { return ts_off_sub(nst, nt) + (size_t)kSubTickets * 32; }
+__host__ __device__ constexpr size_t ts_off_lcnt(int nst, int nt) { return ts_off_order(nst, nt) + 2 * ts_align4((size_t)nt); }
+__host__ __device__ constexpr size_t ts_off_lflag(int nst, int nt) { return ts_off_lcnt(nst, nt) + 2 * ts_align4((size_t)nt); }
+__host__ __device__ constexpr size_t ts_meta_words(int nst, int nt) { return ts_off_lflag(nst, nt) + 4; }
 static_assert(ts_off_items(150, 75) % 4 == 0 && ts_off_hdr(150, 75) % 4 == 0 && ts_off_ticket(150, 75) % 2 == 0 &&
               ts_off_pool(150, 75) % 2 == 0 && ts_off_dir(150, 75) % 2 == 0 && ts_off_dbg(150, 75) % 2 == 0 &&
               ts_off_cnt4(150, 75) % 4 == 0,
@@ -178,6 +192,15 @@ __host__ __device__ inline unsigned long long *ts_dbg(const TileStore &S) {
 __host__ __device__ inline unsigned long long *ts_sub(const TileStore &S, uint32_t g) {
     return reinterpret_cast<unsigned long long *>(S.meta + ts_off_sub(S.nst, S.ntiles) + (size_t)g * 32);
 }
+__host__ __device__ inline uint32_t *ts_order(const TileStore &S, int parity) {
+    return S.meta + ts_off_order(S.nst, S.ntiles) + (size_t)parity * ts_align4((size_t)S.ntiles);
+}
+__host__ __device__ inline uint32_t *ts_lcnt(const TileStore &S, int parity) {
+    return S.meta + ts_off_lcnt(S.nst, S.ntiles) + (size_t)parity * ts_align4((size_t)S.ntiles);
+}
+__host__ __device__ inline uint32_t *ts_lflag(const TileStore &S) { return S.meta + ts_off_lflag(S.nst, S.ntiles); }
+// (lean frames: T1's workgroups add their colour-chunk counts to the second 8-byte word of the sub-ticket lines)
+__host__ __device__ inline unsigned long long *ts_sub_colour(const TileStore &S, uint32_t g) { return ts_sub(S, g) + 1; }
 __host__ __device__ inline uint4 *ts_cnt4(const TileStore &S) { return reinterpret_cast<uint4 *>(S.meta + ts_off_cnt4(S.nst, S.ntiles)); }
 __host__ __device__ inline unsigned long long *ts_dir(const TileStore &S) {
     return reinterpret_cast<unsigned long long *>(S.meta + ts_off_dir(S.nst, S.ntiles));
@@ -235,8 +258,13 @@ int order_quality(hipStream_t s, const float *bounds, uint64_t n, float *ratio, 
 // resets depth / accumulators under the tiles T1's epilogue decided to split (what the epilogue itself does when
 // launch_project_bin's clear_split is set); for frames whose T1 overlapped the previous frame's tail
 void launch_reset_split(hipStream_t s, int W, int H, const TileStore &S, uint32_t *depth, uint32_t *acc);
+// write_acc bit 3 (mode 0): a LEAN frame (see ts_off_order) -- T1 ran without epilogue (launch_project_bin's flag 8);
+// bit 4 (modes 0, 1): the frame's parity (which lcnt[] half its workgroups write, which order[] they read; the
+// launch's extra workgroup writes the OTHER order[])
 void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, float window, uint32_t *depth,
                  uint32_t *acc, uint8_t *img, int write_acc, const TilePyr *pyr, const Sliced *depth_slices = nullptr);
+// folds the statistics of the lean frame of parity `parity` into the store's header now (rtr_frame_stats)
+void launch_lean_fold(hipStream_t s, int W, int H, const TileStore &S, int parity);
 void launch_stream_probe(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *sink, int variant);
 void launch_resolve(hipStream_t s, const uint32_t *acc, uint8_t *img, size_t npix);
 // img_slices (4 levels only): read the input image from the ranks' resolved slices (chunk in pixels);

@@ -368,10 +368,15 @@ constexpr int kTileThreadsCompact = RTR_TILE0_THREADS;  // k_tile<0> (see tile_b
 #define RTR_TILE0_BATCH 8
 #endif
 constexpr int kTileBatch = RTR_TILE_BATCH;    // entries in flight per thread in k_tile
+#ifndef RTR_T1_PAIRS
+#define RTR_T1_PAIRS 0  // 1: the packed point kernel handles two chunks per iteration (measured slower, see k_project_bin)
+#endif
 #ifndef RTR_T1_WAVES
-#define RTR_T1_WAVES 4  // the point kernel runs 4 waves per SIMD (1024 workgroups); capping it at 80 registers so that a
-#endif                  // tile workgroup of the previous frame fits beside it (option "overlap") spills in the hot loop:
-                        // +25 us alone, and the co-running tile kernel slows it further (measured: 0.333 vs 0.296 ms)
+#define RTR_T1_WAVES 5  // the packed point kernel: five waves per SIMD (96 registers, four of them spilled to scratch in the
+#endif                  // long path only; round 4: 126-129 us against 127-133 at four, six -- 80 registers, 51 spilled -- 180);
+                        // the fp32 and the culling forms stay at four (their grid is four workgroups per CU anyway).
+                        // (Capping it at 80 registers so that a tile workgroup of the previous frame fits beside it --
+                        // option "overlap" -- spills in the hot loop: +25 us alone, measured 0.333 vs 0.296 ms.)
 constexpr int kSplitGrid = 256; // workgroups of the mode-3 launch (they stride over the split tiles' slices)
 constexpr int kPer2 = kTileBatch / 2, kPer4 = kTileBatch / 4;  // registers per stream of a 2- / 4-stream tile
 constexpr int kMaxGroups = RTR_MAX_GROUPS;    // tile groups of a quad that get a wave-level claim; the rest claim per lane
@@ -419,6 +424,15 @@ __device__ __forceinline__ unsigned long long make_entry(uint32_t depth_bits, ui
 }
 
 __device__ __forceinline__ void store_error(const TileStore &S, uint32_t code) { atomicOr(ts_hdr(S) + kHdrErrLive, code); }
+// ... from the TILE kernels: T1's epilogue has already published this frame's word, so the code also goes straight to the
+// mapped host word (a plain store, like the epilogue's: sticky until the host reads it) -- the synchronising call that
+// returns this frame must not return RTR_OK
+__device__ __forceinline__ void store_error_now(const TileStore &S, uint32_t code) {
+    store_error(S, code);
+    typedef uint32_t __attribute__((address_space(1))) *gu32_t;
+    uint32_t *const host = ts_consts(S)->err_host;
+    if (host) *(volatile gu32_t)host = code;
+}
 
 // Stream position v >= kS0 of storage tile st lies in extent k, which holds [kS0 << (k-1), kS0 << k).
 // The lane that claimed an extent's FIRST position allocates it (one returning add on the pool
@@ -709,25 +723,31 @@ __device__ void bin_epilogue(const TileStore &S, int W, int H, int flags, uint32
 // look alike): tiles with more than twice the mean entry count first, so the few heavy tiles that
 // bound T4 start at once instead of trailing the launch.  One extra workgroup of the tile launch (modes 0
 // and 1), beside the ~2000 that are busy with tiles -- off every critical path.
-__device__ void next_frame_order(const TileStore &S) {
+__device__ void next_frame_order(const TileStore &S, int parity, bool lean = false) {
     __shared__ uint32_t s_w[8];
-    const uint32_t *const tile_cnt = ts_tile_cnt(S);
-    uint32_t *const perm = ts_perm(S);
+    // (a lean frame orders by the PREVIOUS lean frame's counts: its own are being written by the tile workgroups right now)
+    const uint32_t *const tile_cnt = lean ? ts_lcnt(S, parity ^ 1) : ts_tile_cnt(S);
+    // (the launch of parity p writes order[p ^ 1]: the tile workgroups of a lean frame may still be reading order[p])
+    uint32_t *const perm = ts_perm(S), *const order = ts_order(S, parity ^ 1);
     const int t = threadIdx.x, nt = S.ntiles, step = blockDim.x;
     const uint32_t thr = 2u * (ts_hdr(S)[kHdrEntries] / (uint32_t)nt) + 1u;
     const StoreConsts *const sc = ts_consts(S);
     const uint32_t heavy = sc->heavy;
     uint32_t big = 0, all = 0, over = 0;
     const int per = (nt + step - 1) / step, lo = t * per;  // contiguous tiles per thread: positions stay tile-ordered
-    for (int k = 0; k < per; ++k)
+    // (every count is read once; per <= 32: nt <= 4096)
+    uint32_t big_mask = 0;
+    for (int k = 0; k < per && k < 32; ++k)
         if (lo + k < nt) {
+            const uint32_t c = tile_cnt[lo + k];
             all += 1;
-            big += tile_cnt[lo + k] > thr ? 1u : 0u;
-            over += tile_cnt[lo + k] > heavy ? 1u : 0u;
+            big += c > thr ? 1u : 0u;
+            big_mask |= (c > thr ? 1u : 0u) << k;
+            over += c > heavy ? 1u : 0u;
         }
     // Tiles above the split threshold in this frame -> a mapped host word: the host launches k_tile_split behind a
     // whole frame only while this has been non-zero lately (rtr_ctx::split_host; read without a sync).
-    {
+    if (!lean) {  // (workgroup-uniform; a lean frame reports through lean_fold)
         typedef uint32_t __attribute__((address_space(1))) *gu32_t;
         const int any_over = __syncthreads_or(over != 0u);
         if (t == 0 && sc->split_host) *(volatile gu32_t)sc->split_host = any_over ? 1u : 0u;
@@ -735,13 +755,103 @@ __device__ void next_frame_order(const TileStore &S) {
     uint32_t n_big = 0, n_all = 0;
     uint32_t big_before = block_scan(big, s_w, n_big) - big;
     uint32_t all_before = block_scan(all, s_w, n_all) - all;
-    for (int k = 0; k < per; ++k)
+    for (int k = 0; k < per && k < 32; ++k)
         if (lo + k < nt) {
-            const bool b = tile_cnt[lo + k] > thr;
-            perm[lo + k] = b ? big_before : n_big + (all_before - big_before);
+            const bool b = (big_mask >> k) & 1u;
+            const uint32_t pos = b ? big_before : n_big + (all_before - big_before);
+            perm[lo + k] = pos;
+            order[pos] = (uint32_t)(lo + k);
             big_before += b ? 1u : 0u;
             all_before += 1u;
         }
+}
+
+// Lean frames (rtr_kernels.h, ts_off_order).  lean_fold: the per-tile entry counts the tile workgroups of the lean frame
+// of parity q stored -> the header words rtr_frame_stats reports and T1 / the host steer by; run by the NEXT lean frame's
+// extra workgroup (the frame is complete then) or by rtr_frame_stats.  One workgroup; s_w: 3 x 8 words of LDS.
+__device__ void lean_fold(const TileStore &S, int q, uint32_t *s_w /*[24]*/) {
+    uint32_t *const flag = ts_lflag(S) + q;
+    if (*flag == 0u) return;  // (workgroup-uniform: nothing to fold, or folded already)
+    const uint32_t *const cnt = ts_lcnt(S, q);
+    const StoreConsts *const sc = ts_consts(S);
+    const uint32_t heavy = sc->heavy;
+    uint32_t sum = 0, mx = 0, over = 0;
+    for (int tile = threadIdx.x; tile < S.ntiles; tile += blockDim.x) {
+        const uint32_t c = cnt[tile];
+        sum += c;
+        mx = c > mx ? c : mx;
+        over += c > heavy ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off, 64);
+        over += __shfl_xor(over, off, 64);
+        const uint32_t o = __shfl_xor(mx, off, 64);
+        mx = o > mx ? o : mx;
+    }
+    const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_w[wv] = sum, s_w[8 + wv] = mx, s_w[16 + wv] = over;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sum = mx = over = 0;
+        for (int k = 0; k < nw; ++k) {
+            sum += s_w[k];
+            mx = s_w[8 + k] > mx ? s_w[8 + k] : mx;
+            over += s_w[16 + k];
+        }
+        uint32_t *const hdr = ts_hdr(S);
+        hdr[kHdrItems] = (uint32_t)S.ntiles;
+        hdr[kHdrSplitItems] = 0u;
+        hdr[kHdrEntries] = sum;
+        hdr[kHdrHeaviest] = mx;
+        hdr[kHdrSlice] = sc->slice < 1u ? 1u : sc->slice;
+        hdr[kHdrSplitTiles] = 0u;  // (a lean frame splits nothing: tiles above the threshold were done by one workgroup each)
+        typedef uint32_t __attribute__((address_space(1))) *gu32_t;
+        if (sc->split_host) *(volatile gu32_t)sc->split_host = over ? 1u : 0u;  // ... and reported: the split launch comes back
+        *flag = 0u;
+    }
+}
+// The extra workgroup of a lean frame's tile launch: what T1's epilogue does for the other frames, minus everything
+// the tile workgroups now do for themselves.  T1 of this frame is complete (kernel boundary), the next T1 has not begun.
+__device__ void lean_frame_end(const TileStore &S, int parity) {
+    uint32_t *const hdr = ts_hdr(S);
+    const int t = threadIdx.x;
+    if (t < 64) {  // colour-chunk counts of this frame's T1 (one word per sub-ticket line)
+        unsigned long long cc = 0ull;
+        if (t < kSubTickets) {
+            cc = *ts_sub_colour(S, (uint32_t)t);
+            *ts_sub_colour(S, (uint32_t)t) = 0ull;
+        }
+        uint32_t c32 = (uint32_t)cc;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c32 += __shfl_xor(c32, off, 64);
+        if (t == 0) {
+            hdr[kHdrColourChunks] = c32;
+            const StoreConsts *const sc = ts_consts(S);
+            const uint32_t err = __hip_atomic_load(hdr + kHdrErrLive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hdr[kHdrError] = err;
+            if (err) {
+                typedef uint32_t __attribute__((address_space(1))) *gu32_t;
+                hdr[kHdrErrLive] = 0u;
+                if (sc->err_host) *(volatile gu32_t)sc->err_host = err;
+            }
+            *ts_pool(S) = 0ull;
+            ts_lflag(S)[parity] = 1u;  // (this frame's counts are on their way: the next fold takes them)
+        }
+    }
+    __shared__ uint32_t s_fold[24];
+    lean_fold(S, parity ^ 1, s_fold);
+    __syncthreads();
+    next_frame_order(S, parity, true);
+}
+__global__ __launch_bounds__(kBlock) void k_lean_fold(TileStore S, int parity) {
+    __shared__ uint32_t s_fold[24];
+    lean_fold(S, parity, s_fold);
+}
+void launch_lean_fold(hipStream_t s, int W, int H, const TileStore &S, int parity) {
+    (void)W, (void)H;
+    hipLaunchKernelGGL(k_lean_fold, dim3(1), dim3(kBlock), 0, s, S, parity);
 }
 
 // PackedXyz helpers ---------------------------------------------------------------
@@ -756,6 +866,14 @@ __device__ __forceinline__ AxisRaw ld_axis(const uint8_t *block, uint32_t b, int
     const uint32_t dw = (b * (uint32_t)lane) >> 3;  // (4 b l) >> 5
     const u32x4_a4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4 *>(block + 4u * dw));
     return AxisRaw{{v.x, v.y, v.z, v.w}};
+}
+// the first 8 of those 16 bytes: all of the lane's FIRST value (shift <= 28, b <= 25) -- what T1's lane test reads
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+struct AxisLo { uint32_t d[2]; };
+__device__ __forceinline__ AxisLo ld_axis_lo(const uint8_t *block, uint32_t b, int lane) {
+    const uint32_t dw = (b * (uint32_t)lane) >> 3;
+    const u32x2_a4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_a4 *>(block + 4u * dw));
+    return AxisLo{{v.x, v.y}};
 }
 // value k = base | bits [b k, b k + b) of the lane's realigned data.  Branch-free for every b <= 25 (b = 0: the mask is
 // empty and the value is the base): the lane's 128 bits are shifted down by its sub-dword offset (four v_alignbit
@@ -885,7 +1003,7 @@ static LaneTest lane_test_consts(const Proj &P, int W, int H, const float absmax
 }
 
 template <bool CULL, bool GROUPS, bool PACKED>
-__global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
+__global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void k_project_bin(const float4 *__restrict__ x4, const float4 *__restrict__ y4,
                                                         const float4 *__restrict__ z4,
                                                         const uint4 *__restrict__ rgba4, uint32_t n4, Proj P, int W,
                                                         int H, TileStore S, const float *__restrict__ bounds,
@@ -964,13 +1082,13 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
         return __ballot(front && !out) != 0ull;
     };
     // a lane's first value of an axis block (b <= 25; b = 0: the mask is empty, the value is the base)
-    auto first_value = [&](const AxisRaw &r, uint32_t b, uint32_t base) -> float {
+    auto first_value = [&](uint32_t d0, uint32_t d1, uint32_t b, uint32_t base) -> float {
         uint32_t vbase = base, x;
         asm("" : "+v"(vbase));
         uint32_t sh;  // 4 b l; alignbit takes its low five bits.  (Written out: the compiler drops the mask on b, then no
                       // longer knows the factor to be small and emits the quarter-rate 32-bit multiply.)
         asm("v_mul_u32_u24 %0, %1, %2" : "=v"(sh) : "s"(b << 2), "v"(lane));
-        const uint32_t e0 = __builtin_amdgcn_alignbit(r.d[1], r.d[0], sh);
+        const uint32_t e0 = __builtin_amdgcn_alignbit(d1, d0, sh);
         const uint32_t mask = (1u << b) - 1u;
         asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(x) : "v"(e0), "s"(mask), "v"(vbase));
         return __uint_as_float(x);
@@ -1148,6 +1266,90 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
         }
     };
 
+#if RTR_T1_PAIRS
+    if (!CULL && PACKED) {
+        // Two chunks per wave and iteration (a PAIR: chunks 2 p and 2 p + 1, neighbours in memory, their two headers one
+        // 64-byte scalar load), light path first: a lane loads only the 8 bytes per axis that hold its first value, runs
+        // the lane test on both chunks, requests the next pair's 8-byte pieces and the pair after that's headers, and
+        // only then turns to the chunks that have a candidate lane -- those are read again in full (16 bytes per lane and
+        // axis: the lines were fetched a moment ago), decoded and taken through do_quad, by ONE copy of that code in a
+        // two-trip loop.  Per wave twice the bytes in flight of the one-chunk pipeline at the same register cost (2 x 6
+        // instead of 12 dwords), half the loop bookkeeping per chunk, and the stream keeps running while a chunk inside
+        // the frustum is worked through.  The 8-byte pieces touch every cache line of the blocks (lane stride b / 2
+        // bytes <= 12.5), so HBM traffic is what it was.
+        const uint32_t npairs = (nchunks + 1u) >> 1;
+        const uint32_t Rp = (npairs + NW - 1u) / NW;
+        const uint32_t phase_p = (uint32_t)((uint64_t)((blockIdx.x * G) / gridDim.x) * Rp / G);
+        auto pair_of = [&](uint32_t q) -> uint32_t {
+            uint32_t r = q + phase_p;
+            r = r >= Rp ? r - Rp : r;
+            const uint32_t p = r * NW + wave;
+            return (q < Rp && p < npairs) ? p : npairs;
+        };
+        struct Half { uint32_t bx, by, bz, ww, off_lo, off_hi, sp; };  // one chunk's header (scalars)
+        auto lo_of = [&](const Half &h, AxisLo out[3]) {
+            const uint8_t *p = reinterpret_cast<const uint8_t *>(pk_planes) + (((((uint64_t)h.off_hi) << 32) | (uint64_t)h.off_lo) << 5);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const uint32_t b = (h.ww >> (6 * a)) & 63u;
+                out[a] = ld_axis_lo(p, b, lane);
+                p += 32u * b;
+            }
+        };
+        uint4 g0, g1, g2, g3;  // the requested pair's headers
+        uint32_t gp = 0, pc = 0;
+        bool gvalid = false, pvalid = false;
+        Half hA{}, hB{};
+        AxisLo rawA[3], rawB[3];
+        auto fetch_hdr = [&](uint32_t q) {
+            const uint32_t pr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(q < Rp ? pair_of(q) : npairs));
+            gvalid = pr < npairs;
+            gp = gvalid ? pr : npairs - 1u;
+            const uint4 *h = pk_hdr + 4 * (size_t)gp;  // (an odd chunk count: the header array ends with a zero header)
+            g0 = h[0], g1 = h[1], g2 = h[2], g3 = h[3];
+        };
+        auto fetch_lo = [&]() {  // of the pair whose headers have arrived
+            pc = gp, pvalid = gvalid;
+            hA = Half{g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z};
+            hB = Half{g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z};
+            lo_of(hA, rawA);
+            lo_of(hB, rawB);
+        };
+        auto light = [&](const AxisLo raw[3], const Half &h, bool live) -> bool {  // wave-uniform: some lane is a candidate
+            if (__ballot(live) == 0ull) return false;
+            const uint32_t sp_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.sp);
+            if (!(lane_test && !(h.ww & kPackWideFlag) && sp_c < 0x7F000000u)) return true;
+            const float x0 = first_value(raw[0].d[0], raw[0].d[1], h.ww & 63u, h.bx);
+            const float y0 = first_value(raw[1].d[0], raw[1].d[1], (h.ww >> 6) & 63u, h.by);
+            const float z0 = first_value(raw[2].d[0], raw[2].d[1], (h.ww >> 12) & 63u, h.bz);
+            return lane_maybe(x0, y0, z0, __uint_as_float(sp_c), live);
+        };
+        fetch_hdr(0);
+        fetch_lo();
+        fetch_hdr(1);
+        for (uint32_t q = 0; q < Rp; ++q) {
+            const Half cA = hA, cB = hB;
+            const uint32_t iA = pc * 128u + (uint32_t)lane, iB = iA + 64u;
+            const bool liveA = pvalid && iA < n4, liveB = pvalid && iB < n4;
+            const bool candA = light(rawA, cA, liveA), candB = light(rawB, cB, liveB);
+            fetch_lo();
+            fetch_hdr(q + 2);
+#pragma unroll 1
+            for (int hh = 0; hh < 2; ++hh) {  // (not unrolled: one copy of the long path)
+                if (!(hh ? candB : candA)) continue;
+                const Half c = hh ? cB : cA;
+                const uint32_t i = hh ? iB : iA;
+                const bool live = hh ? liveB : liveA;
+                const ChunkRaw raw = load_chunk(pk_planes, make_uint4(c.bx, c.by, c.bz, c.ww), make_uint4(c.off_lo, c.off_hi, 0u, 0u), lane);
+                float4 X, Y, Z;
+                Rows r;
+                unpack_chunk(raw, c.ww, c.bx, c.by, c.bz, X, Y, Z, lane);
+                project_rows(X, Y, Z, r);
+                do_quad(i < n4 ? i : n4 - 1u, live, r);  // (masked lanes: any valid address for the colour load)
+            }
+        }
+    } else
+#endif
     if (!CULL && PACKED) {
         // the same pipeline as below on the packed form, one stage deeper: header of chunk q + 2, planes of chunk
         // q + 1 (<= 12 dwords per lane, usually 6-9) and the arithmetic of chunk q are in flight together
@@ -1198,8 +1400,9 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
             bool cand = true;
             const uint32_t sp_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)spb);
             if (lane_test && !(ww & kPackWideFlag) && sp_c < 0x7F000000u) {
-                const float x0 = first_value(raw.a[0], ww & 63u, bx), y0 = first_value(raw.a[1], (ww >> 6) & 63u, by);
-                const float z0 = first_value(raw.a[2], (ww >> 12) & 63u, bz);
+                const float x0 = first_value(raw.a[0].d[0], raw.a[0].d[1], ww & 63u, bx);
+                const float y0 = first_value(raw.a[1].d[0], raw.a[1].d[1], (ww >> 6) & 63u, by);
+                const float z0 = first_value(raw.a[2].d[0], raw.a[2].d[1], (ww >> 12) & 63u, bz);
                 cand = lane_maybe(x0, y0, z0, __uint_as_float(sp_c), live_c);
             }
             if (cand) {
@@ -1314,6 +1517,12 @@ __global__ __launch_bounds__(kBlock, RTR_T1_WAVES) void k_project_bin(const floa
                 do_quad(ic, live, r);
             }
         }
+    }
+    if (clear_split & 8) {
+        // a LEAN frame (lean_frame_end): no ticket, no epilogue -- the tile kernel's workgroups read the stream counters
+        // themselves.  Only the colour-chunk statistic leaves, one fire-and-forget add per wave that has any.
+        if (lane == 0 && n_colour) atomicAdd(ts_sub_colour(S, wave & (uint32_t)(kSubTickets - 1)), (unsigned long long)n_colour);
+        return;
     }
     // every claim of this workgroup has returned (its value was used); the workgroup that takes the
     // last ticket sees every stream length final
@@ -1546,13 +1755,16 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
     // tiles its occupancy bitmap lists (T1's epilogue: tiles with entries), so a tile WITHOUT local entries
     // is not written at all -- with N ranks ~(N - 1) / N of the tiles of a rank's two tile passes
     const bool sparse = (write_acc & 4) != 0;
+    const bool lean = MODE == 0 && (write_acc & 8) != 0;  // (see lean_frame_end)
+    const int lean_parity = (write_acc >> 4) & 1;          // (every mode-0 / mode-1 launch: which order[] NOT to write)
     write_acc &= 1;
     const uint4 *const records = reinterpret_cast<const uint4 *>(ts_items(S));
     // Records [0, ntiles): one tile each, for workgroups 0 .. ntiles - 1; records [ntiles, ...): the slices of
     // split tiles, dealt round-robin to the remaining workgroups (mode 3: to all of them) up to kItemEnd.
     const uint32_t nt = (uint32_t)g.ntiles;
     if ((MODE == 0 || MODE == 1) && blockIdx.x == gridDim.x - 1) {  // one extra workgroup, beside ~2000 busy ones
-        next_frame_order(S);
+        if (lean) lean_frame_end(S, lean_parity);
+        else next_frame_order(S, lean_parity);
         return;
     }
     const bool tile_wg = MODE != 3 && MODE != 5 && blockIdx.x < nt;
@@ -1592,6 +1804,31 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
             const uint4 c4 = ts_cnt4(S)[item_i];
             rec0 = make_uint4(item_i, c4.x, c4.y, c4.z);
             rec1 = make_uint4(c4.w, 0u, 0u, 0u);
+        } else if (MODE == 0 && lean) {
+            // a lean frame: no work list -- the tile of this launch position, its stream counters read here (T1 is
+            // complete) and reset for the next frame (each counter belongs to exactly one tile), its entry count stored
+            // for the frame's statistics
+            const uint32_t tl = ts_order(S, lean_parity)[item_i];
+            const int ltx = (int)tl % g.tiles_x, lty = (int)tl / g.tiles_x;
+            uint32_t *const fill = ts_fill(S);
+            uint32_t f[4] = {0u, 0u, 0u, 0u};
+            const int nsl = 2 << (g.tw_shift - 5);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int st = q < nsl ? stream_tile(g, ltx, lty, q) : -1;
+                if (st >= 0) f[q] = fill[(size_t)st << S.fill_shift];
+            }
+            rec0 = make_uint4(tl, f[0], f[1], f[2]);
+            rec1 = make_uint4(f[3], 0u, 0u, 0u);
+            __syncthreads();  // every wave has read the counters before they are reset
+            if (tid == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int st = q < nsl ? stream_tile(g, ltx, lty, q) : -1;
+                    if (st >= 0 && f[q]) fill[(size_t)st << S.fill_shift] = 0u;
+                }
+                ts_lcnt(S, lean_parity)[tl] = f[0] + f[1] + f[2] + f[3];  // (summed up by the next fold)
+            }
         } else {
             rec0 = records[2 * (size_t)item_i], rec1 = records[2 * (size_t)item_i + 1];
         }
@@ -1676,7 +1913,7 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
                         s_seg_n[q] = (uint32_t)(hi - e_lo);
                         s_seg_pb[q] = stream_pb(s);
                     } else {
-                        store_error(S, 4u);  // (more pieces than the table holds: entries would be dropped)
+                        store_error_now(S, 4u);  // (more pieces than the table holds: entries would be dropped)
                     }
                 }
             }
@@ -2189,7 +2426,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_split(TileStore S, TileGe
         int polls = 0;
         while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_split) {
             if (++polls > (1 << 22)) {
-                store_error(S, 8u);
+                store_error_now(S, 8u);
                 break;
             }
             __builtin_amdgcn_s_sleep(8);
@@ -2200,10 +2437,12 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_split(TileStore S, TileGe
     tile_body<3>(S, g, W, H, window, depth, acc, img, write_acc, pyr, nosl);
 }
 
+constexpr int kGridCacheDevices = 64;
 void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, const TileStore &S,
                         const float *bounds, int clear_split, int phases, int xp, hipEvent_t ev_start, hipEvent_t ev_stop) {
     uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) {
+        if (clear_split & 8) return;  // (a lean frame: the stream counters are zero and stay so)
         hipExtLaunchKernelGGL(k_bin_empty, dim3(1), dim3(kBlock), 0, s, ev_start, ev_stop, 0, W, H, S, clear_split);
         return;
     }
@@ -2220,20 +2459,27 @@ void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int
     // per wave instead of 3 KB, so the packed kernels take a fifth workgroup per CU when their registers admit it (<= 96:
     // a build at 100 registers launched with the fixed 1280 of before ran 170 instead of 140 us); asked of the runtime
     // once per kernel.
-    auto default_grid = [&](auto kernel, int &cached) -> int {
+    // (cached per kernel AND device: contexts on different devices must not share the first caller's CU count; the
+    // table is written with relaxed atomics -- two threads that race compute the same value)
+    int dev_now = 0;
+    if (hipGetDevice(&dev_now) != hipSuccess || dev_now < 0 || dev_now >= kGridCacheDevices) dev_now = kGridCacheDevices;
+    auto default_grid = [&](auto kernel, int *cache) -> int {
+        int cached = dev_now < kGridCacheDevices ? __atomic_load_n(&cache[dev_now], __ATOMIC_RELAXED) : 0;
         if (cached == 0) {
-            int per_cu = 0, dev = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1)
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_now < kGridCacheDevices ? dev_now : 0) != hipSuccess ||
+                per_cu < 1 || cus < 1)
                 cached = kDefaultPointGrid;
             else
                 cached = cus * (per_cu < 4 ? per_cu : (packed && per_cu >= 5 ? 5 : 4));
+            if (dev_now < kGridCacheDevices) __atomic_store_n(&cache[dev_now], cached, __ATOMIC_RELAXED);
         }
         return cached;
     };
 #define RTR_T1(CULL, GROUPS, PACKED)                                                                                          \
     do {                                                                                                                      \
-        static int cached_grid = 0;                                                                                           \
+        static int cached_grid[kGridCacheDevices] = {0};                                                                      \
         const dim3 grid(point_grid(n4, c.grid == kDefaultPointGrid ? default_grid(k_project_bin<CULL, GROUPS, PACKED>, cached_grid) : c.grid)); \
         hipExtLaunchKernelGGL((k_project_bin<CULL, GROUPS, PACKED>), grid, block, 0, s, ev_start, ev_stop, 0, x, y, z, col,    \
                               (uint32_t)n4, P, W, H, S, CULL ? bounds : (packed ? nullptr : c.spread), clear_split,          \
@@ -2471,7 +2717,7 @@ void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, floa
     const dim3 grid(g.ntiles + kHeavyExtra), grid1(g.ntiles + kHeavyExtra + 1), block(kTileThreads);
     if (mode == 0)  // (the tiles + one workgroup for the next frame's launch order; split tiles' slices: k_tile_split)
         hipLaunchKernelGGL(k_tile<0>, dim3(g.ntiles + 1), dim3(kTileThreadsCompact), 3 * tpix * sizeof(uint32_t) + 3 * tpix, s, S, g, W, H,
-                           window, depth, acc, img, write_acc & 1, pyr ? *pyr : none, nosl);
+                           window, depth, acc, img, write_acc & (1 | 8 | 16), pyr ? *pyr : none, nosl);  // (8, 16: lean frame, parity)
     else if (mode == 3)  // the split tiles' slices, min phase then second phase: every workgroup leaves at once on ordinary frames
         hipLaunchKernelGGL(k_tile_split, dim3(kSplitGrid), block, 5 * tpix * sizeof(uint32_t) + 3 * tpix, s, S, g, W, H, window, depth,
                            acc, img, write_acc & 1, pyr ? *pyr : none, nosl);
@@ -2479,7 +2725,7 @@ void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, floa
         hipLaunchKernelGGL(k_tile<4>, dim3(g.ntiles), block, lds + tpix * sizeof(uint32_t) + kSegCap4 * 16, s, S, g, W, H, window, depth,
                            acc, img, write_acc & 1, pyr ? *pyr : none, *depth_slices);
     else if (mode == 1)
-        hipLaunchKernelGGL(k_tile<1>, grid1, block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & 6, none, nosl);
+        hipLaunchKernelGGL(k_tile<1>, grid1, block, lds, s, S, g, W, H, window, depth, acc, img, write_acc & (6 | 16), none, nosl);
     else  // mode 2 always writes the accumulators; bit 1 of write_acc = overwrite; pyr: also emit the pyramid
         hipLaunchKernelGGL(k_tile<2>, grid, block, lds, s, S, g, W, H, window, depth, acc, img, 1 | (write_acc & 6),
                            pyr ? *pyr : none, depth_slices ? *depth_slices : nosl);

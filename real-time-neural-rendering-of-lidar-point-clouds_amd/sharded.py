@@ -55,7 +55,16 @@ class HipLocal:
     def __init__(self, projector):
         self.p = projector
         self._views = None
-        self.p2p_res = None  # resolution the peers' buffers are mapped for (shared by every renderer on this context)
+        self._p2p_res = None  # resolution the peers' buffers are mapped for (shared by every renderer on this context)
+
+    @property
+    def p2p_res(self):
+        """None unless the library still holds the peers' mappings: a new cloud or resolution on this context closes the
+        exchange on the C side (rtr.h, "p2p_open"), and the next sharded frame must run p2p_setup again -- on every
+        rank, which is the case when every rank replaced its shard."""
+        if self._p2p_res is not None and not self.p.get_option("p2p_open"):
+            self._p2p_res = None
+        return self._p2p_res
 
     def bind_stream(self):
         """Run the kernels on torch's current stream so RCCL collectives order with them."""
@@ -113,10 +122,10 @@ class HipLocal:
         if bad:
             raise RuntimeError("rtr_p2p_export failed: %s" % "; ".join(map(str, bad)))
         self.p.p2p_open(rank, world, blocks)
-        self.p2p_res = (self.p.W, self.p.H)
+        self._p2p_res = (self.p.W, self.p.H)
 
     def p2p_close(self):
-        self.p2p_res = None
+        self._p2p_res = None
         self.p.p2p_close()
 
     def p2p_min_depth(self):

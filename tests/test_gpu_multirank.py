@@ -48,3 +48,26 @@ def test_two_rank_bench_matches_oracle(extra):
     # ... and the owner-computes form (every tile produced once, the frame's owner rotating over the ranks)
     assert out["exchange"]["owned_clean_on_all_ranks"] is True, out["exchange"]
     assert out["exchange"]["used"] in ("owned", "p2p", "collective")
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE in the environment: bench.py starts the two rank
+    processes itself (children of a process that never touches the GPU), prints rank 0's one JSON line and exits 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--points", "3000000",
+           "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-weak", "--exchange", "collective"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["parity_vs_oracle"] is True
+
+
+def test_self_launch_reports_a_failing_rank():
+    """... and a rank that fails makes the whole command fail (an unknown scene name is refused by every rank)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--points", "1000",
+           "--set", "no_such_option=1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-weak"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode != 0

@@ -821,3 +821,51 @@ def test_parameter_sweep(pkg, orc, projector, levels, window, strength, thr):
             assert np.array_equal(projector.download(pkg._lib.BUF_MINMAX), rf["minmax"]), phases
     finally:
         projector.set_params(depth_window=0.02, filter_strength=1.025, gradient_threshold=0.03, levels=4)
+
+
+def test_lean_frames_match_the_epilogue_form(pkg, orc, projector):
+    """Option "lean" (default): whole frames end the point kernel without its epilogue -- the tile workgroups read and
+    reset the stream counters themselves, an extra workgroup keeps the books.  Same frames, same statistics as with the
+    epilogue (lean = 0), across switches between the two forms, the phase calls in between, an empty cloud, a
+    resolution with 64-wide tiles, and the colour-chunk / entry counts bench.py prices the kernel by."""
+    n, W, H = 400_000, 640, 480
+    xyzw, rgba = orc.generate("room_shell", 0xC0FFEE07, 0, n, n)
+    projector.upload_points(xyzw, rgba)
+    projector.set_resolution(W, H)
+    poses = [pkg.orbit_projection(k, W, H) for k in (0, 140, 275, 410, 555, 690, 835, 970)]
+    stats = {}
+    for lean in (1, 0, 1):
+        projector.set_option("lean", lean)
+        for k, P in enumerate(poses):
+            filtered = bool(k & 1)
+            img, depth = projector.project(P, filtered=filtered)
+            st = projector.frame_stats()
+            assert st["errors"] == 0 and st["items"] == (W // 32) * (H // 32) and st["split_items"] == 0
+            stats.setdefault(k, []).append((st["entries"], st["heaviest_tile"], st["colour_chunks"]))
+            ref = orc.project(xyzw, rgba, P, W, H)
+            rd, ri = ref["depth_bits"], ref["img"]
+            if filtered:
+                rf = orc.filter(rd, ri)
+                rd, ri = rf["depth"].view(np.uint32), rf["img"]
+            assert np.array_equal(depth.view(np.uint32), rd) and np.array_equal(img, ri), (lean, k)
+            if k == 3:  # the phase calls between two lean frames (they bin for themselves)
+                projector.clear(); projector.min_depth_pass(P); projector.accumulate_pass(P); projector.resolve()
+                assert np.array_equal(projector.download(pkg._lib.BUF_DEPTH), ref["depth_bits"])
+                assert np.array_equal(projector.download(pkg._lib.BUF_IMAGE), ref["img"])
+    for k, rows in stats.items():
+        assert rows[0] == rows[1] == rows[2] and rows[0][0] > 0, (k, rows)
+    # frames WITHOUT a statistics call in between (the next lean frame folds the previous one's), then the last one's
+    projector.set_option("lean", 1)
+    for P in poses:
+        projector.render(P, True)
+    st = projector.frame_stats()
+    assert (st["entries"], st["heaviest_tile"], st["colour_chunks"]) == stats[len(poses) - 1][0]
+    # 64-wide tiles (four streams per tile) and an empty cloud
+    projector.set_resolution(3840, 2160)
+    P4 = pkg.orbit_projection(3, 3840, 2160)
+    img, depth = projector.project(P4)
+    ref = orc.project(xyzw, rgba, P4, 3840, 2160)
+    assert np.array_equal(depth.view(np.uint32), ref["depth_bits"]) and np.array_equal(img, ref["img"])
+    projector.upload_points(np.zeros((0, 4), np.float32), np.zeros((0, 4), np.uint8))
+    img, depth = projector.project(P4)
+    assert (depth.view(np.uint32) == 0x7F7FFFFF).all() and not img.any()

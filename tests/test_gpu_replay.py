@@ -103,3 +103,47 @@ def test_replay_cli_matches_oracle(pkg, orc, tmp_path, traj_kind, filtered, app)
             img, depth = rf["img"], rf["depth"]
         assert np.array_equal(_read_ppm(out / ("frame_%d.ppm" % (k + 1))), img[:, :, ::-1])
         assert np.array_equal(_read_pfm(out / ("frame_%d.pfm" % (k + 1))).view(np.uint32), depth.view(np.uint32))
+
+
+@pytest.mark.parametrize("app", ["python", "cpp"])
+def test_replay_from_a_pcd_oct_cache(pkg, orc, tmp_path, app):
+    """Row N3: the loader's grid cache (`pcd.oct`, Octreegrid.h:53-114; what CloudReader::loadCloud reads when
+    ~/.pcl_cache holds one, cloudreader.cpp:182-190) as the cloud of a replay -- BASELINE C1's cloud (100 k points,
+    seed 0xC0FFEE01) written to a .ply, read back, gridded in 0.25 m blocks and written as a .oct by formats.py, then
+    rendered on the GPU by both replay apps (the C++ example has its own reader) and compared with the oracle on the
+    ORIGINAL cloud: the block order of the file must not matter, the B,G,R byte order must survive."""
+    F = pkg.formats
+    n, W, H = 100_000, 640, 480
+    xyzw, rgba = orc.generate("room_shell", 0xC0FFEE01, 0, n, n)
+    F.write_ply(tmp_path / "c1.ply", xyzw[:, :3], rgba[:, :3])
+    grid = F.compute_grid(*F.read_ply(tmp_path / "c1.ply"))
+    assert len(grid) > 100  # (a real block structure, not one block)
+    F.write_pcd_oct(tmp_path / "pcd.oct", grid)
+    cal = pkg.benchmark_calibration(W, H)
+    F.write_cameras_txt(tmp_path / "cameras.txt", cal)
+    poses = [pkg.orbit_pose(k) for k in (5, 405, 805)]
+    traj = tmp_path / "images.txt"
+    F.write_images_txt(traj, poses)
+    poses_back = [E for E, _ in F.read_trajectory_colmap(traj)]
+    out = tmp_path / "frames"
+    if app == "python":
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "render_trajectory.py")]
+    else:
+        exe = str(tmp_path / "render_trajectory")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "examples", "render_trajectory.cpp"), "-o", exe, pkg.LIB_PATH,
+                               "-Wl,-rpath," + os.path.dirname(pkg.LIB_PATH)])
+        out.mkdir()
+        cmd = [exe]
+    cmd += [str(tmp_path / "pcd.oct"), str(traj), str(tmp_path / "cameras.txt"), "--out", str(out), "--every", "1", "--filtered"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    assert "Loaded %d points" % n in res.stdout
+    cal_back = F.load_calibration(tmp_path / "cameras.txt")
+    bgra = np.ascontiguousarray(rgba[:, [2, 1, 0, 3]])  # the loader stores B,G,R (cloudreader.cpp:168)
+    for k, E in enumerate(poses_back):
+        P = orc.compose_projection(cal_back.getIntrinsicsMatrix(), E)
+        ref = orc.project(xyzw, bgra, P, W, H)
+        rf = orc.filter(ref["depth_bits"], ref["img"])
+        assert np.array_equal(_read_ppm(out / ("frame_%d.ppm" % (k + 1))), rf["img"][:, :, ::-1])
+        assert np.array_equal(_read_pfm(out / ("frame_%d.pfm" % (k + 1))).view(np.uint32), rf["depth"].view(np.uint32))

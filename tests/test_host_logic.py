@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in declared:
         assert hasattr(lib, name), "librtr_hip.so does not export %s" % name
     assert sorted(pkg.SYMBOLS) == declared
-    assert lib.rtr_abi_version() == 1
+    assert lib.rtr_abi_version() == 2
 
 
 def test_default_params(pkg):
