@@ -115,9 +115,20 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          B/pt instead of 12 for spatially ordered clouds (neighbours share sign, exponent and leading
  *          mantissa bits); any bit pattern round-trips (NaNs, -0, mixed signs take 4 bytes).  1 (default):
  *          used when it saves at least 1/8 of the stream; 0: never; 2: always, and the packed form is
- *          decoded and compared with the SoA arrays once (an error if a single point differs).  The SoA
- *          arrays stay resident (+6-9 B/pt).  rtr_get_option: "packed" (1: in use),
- *          "packed_millibytes_per_point" (coordinate stream incl. headers, 12000 = raw).
+ *          decoded and compared with the SoA arrays once (an error if a single point differs).  rtr_get_option:
+ *          "packed" (1: in use), "packed_millibytes_per_point" (coordinate stream incl. headers, 12000 = raw).
+ *  "keep_soa": 0 (default) = a packed cloud is resident in packed form ONLY: the fp32 SoA arrays (12 B per point) are
+ *          freed once the cloud has been packed and decoded again -- bit for bit -- by the calls that read fp32
+ *          coordinates (mode 0 and the phase calls with another matrix, rtr_reorder_points, rtr_download_points,
+ *          option "pack" = 0); 1 = they stay resident beside the packed form.
+ *  "pool_worst_case": 0 (default) = the pool of dynamic stream extents is sized by the frames the cloud has had (8 x the
+ *          most in-frustum entries a completed frame reported, at least n / 4: 2 B per point instead of 16).  A frame
+ *          whose entries jump past that overflows it; the next synchronising call (every call that copies results to the
+ *          host, rtr_synchronize, rtr_download_buffer) then sizes the pool for the worst case and renders that frame
+ *          again before it returns -- transparent, except for whoever consumes frames on the stream without ever
+ *          synchronising, and for rtr_wait (asynchronous outputs), which reports RTR_ERR_INTERNAL once and asks for
+ *          the frame again.  1 = sized for the worst case (2 n entries) from the start.
+ *          rtr_get_option("resident_millibytes_per_point"): device memory held for the cloud and its frames, per point.
  *  "keep_accum": 1 = the whole-frame calls also write RTR_BUF_ACCUM (default 0; the phase
  *          calls always do).
  *  "overlap": 1 = rtr_render queues the point stream (T1) of a frame on a second, internal

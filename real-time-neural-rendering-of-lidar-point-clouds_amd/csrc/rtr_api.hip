@@ -34,6 +34,14 @@ struct rtr_ctx {
     float *spread = nullptr;    // lane spread per 256-point chunk (rtr::Cloud::spread: T1's lane test)
     float absmax[3] = {0.f, 0.f, 0.f};  // largest finite |x|, |y|, |z| of the resident cloud
     int opt_lane_test = 1;      // T1 tests one point per lane first (option "lane_test")
+    int opt_keep_soa = 0;       // 1: the fp32 SoA arrays stay resident beside the packed form (option "keep_soa")
+    int opt_pool_worst = 0;     // 1: the extent pool is always sized for the worst case, 2 n entries (option "pool_worst_case")
+    bool pool_worst = false;    // ... for this cloud: a frame overflowed the adaptive pool, or the peers map it
+    uint32_t *entries_host = nullptr, *entries_dev = nullptr;  // mapped host word: entries of the last frame whose statistics are complete
+    uint64_t entries_max = 0;   // the most entries a completed frame of this cloud has had
+    float last_P[16] = {0};     // the last whole frame (rtr_render): what a synchronising call repeats when it learns that
+    int last_filter = 0;        // the adaptive extent pool was too small for it
+    bool last_valid = false;
     int opt_lean = 1;           // whole single-GPU frames without split tiles end T1 without its epilogue (option "lean")
     bool last_lean = false;     // the last binned frame was a lean one (its statistics are folded on demand) ...
     int lean_parity = 0;        // ... and this was its parity
@@ -259,6 +267,10 @@ void free_lists(rtr_ctx *c) {  // the dynamic extent pools (sized by the point c
     }
     c->list_valid = false;
     c->split_cooldown = kSplitCooldown;  // (a new cloud)
+    c->pool_worst = false;
+    c->entries_max = 0;
+    if (c->entries_host) *c->entries_host = 0u;
+    c->last_valid = false;
 }
 
 void free_pack(rtr_ctx *c) {
@@ -309,6 +321,7 @@ int ensure_tiles(rtr_ctx *c, hipStream_t s) {
     if (c->opt_debug_dyn_cap >= 0 && (uint64_t)c->opt_debug_dyn_cap < want.dyn_cap) want.dyn_cap = (uint64_t)c->opt_debug_dyn_cap;
     want.err_host = c->err_dev;
     want.split_host = c->split_dev;
+    want.entries_host = c->entries_dev;
     want.heavy = c->opt_heavy > 0 ? (uint32_t)c->opt_heavy : 0xFFFFFFFFu;
     want.slice = (uint32_t)c->opt_slice;
     if (memcmp(&want, &f.consts, sizeof want) != 0) {
@@ -318,21 +331,62 @@ int ensure_tiles(rtr_ctx *c, hipStream_t s) {
     return RTR_OK;
 }
 
-// The dynamic extents of one frame sum to less than twice its entries (every extent doubles its
-// stream, rtr_kernels.h), and a frame has at most n entries: 16 B per point, against the 24 B per
-// point of round 1's wave lists + sorted copy.
+// The dynamic extents of one frame sum to less than twice its entries (every extent doubles its stream,
+// rtr_kernels.h), and a frame has at most n entries: 2 n + 64 entries = 16 B per point is the worst case (round 1's
+// wave lists + sorted copy: 24).  An ordinary view has a few per cent of the cloud inside the frustum, so the pool is
+// sized by the frames this cloud has had: 8 x the most entries a completed frame reported (a mapped host word, read
+// without a sync), at least n / 4 and 2^20 -- 2 B per point.  A frame whose entries jump past that (the camera suddenly
+// sees four times more of the cloud than ever before) overflows the pool, reports it (tile-store error 2), and the next
+// synchronising call grows the pool to the worst case and renders the frame again (finish_sync) -- the caller never
+// sees it, unless it consumes frames on the stream without ever synchronising: option "pool_worst_case" is for that.
+hipError_t sync_streams(rtr_ctx *c);
+uint64_t pool_worst_cap(const rtr_ctx *c) { return 2 * c->n + 64; }
+uint64_t pool_want_cap(rtr_ctx *c, uint64_t have) {
+    const uint64_t worst = pool_worst_cap(c);
+    if (c->opt_pool_worst || c->pool_worst || c->p2p.open) return worst;
+    if (c->entries_host) {
+        const uint64_t e = __atomic_load_n(c->entries_host, __ATOMIC_RELAXED);
+        if (e > c->entries_max) c->entries_max = e;
+    }
+    uint64_t floor_ = c->n / 4 > (1ull << 20) ? c->n / 4 : (1ull << 20);
+    // (hysteresis: grown to 8 x when the head-room over the densest frame seen falls under 4 x)
+    uint64_t want = have >= 4 * c->entries_max && have >= floor_ ? have : (8 * c->entries_max > floor_ ? 8 * c->entries_max : floor_);
+    return want < worst ? want : worst;
+}
 int ensure_lists(rtr_ctx *c) {
     auto &f = c->F();
-    if (f.dyn && f.pool_n == c->n) return RTR_OK;
+    const uint64_t want = pool_want_cap(c, f.pool_n == c->n ? f.dyn_cap : 0);
+    if (f.dyn && f.pool_n == c->n && f.dyn_cap >= want) return RTR_OK;
     // (the peers map the pool that was EXPORTED -- set 0's: export / open again after a new cloud.  The second set's
     // pool, first allocated by a frame with option "overlap", is nobody else's business)
     if (&f == &c->fs[0] && (c->p2p.open || c->p2p.red)) p2p_release(c);
+    HIP_TRY(c, sync_streams(c));  // (frames in flight may still read the old pool)
     dfree(f.dyn);
     c->list_valid = false;
-    f.dyn_cap = 2 * c->n + 64;
+    f.dyn_cap = want;
     f.pool_n = c->n;
     HIP_TRY(c, hipMalloc((void **)&f.dyn, f.dyn_cap * sizeof(uint64_t)));
     return RTR_OK;
+}
+
+// The fp32 SoA arrays of a cloud that is resident in packed form only (option "keep_soa" = 0, the default): decoded
+// from the packed form -- bit for bit, it is lossless -- for the calls that read fp32 coordinates (the atomic form, the
+// sort, rtr_download_points, option "pack" = 0, the stream probe).  They stay until the cloud is packed again.
+int ensure_soa(rtr_ctx *c) {
+    if (c->x) return RTR_OK;
+    if (!c->pk_hdr || c->cap == 0) return fail(c, RTR_ERR_INTERNAL, "no resident coordinates");
+    HIP_TRY(c, hipMalloc((void **)&c->x, c->cap * 4));
+    HIP_TRY(c, hipMalloc((void **)&c->y, c->cap * 4));
+    HIP_TRY(c, hipMalloc((void **)&c->z, c->cap * 4));
+    rtr::unpack_to_soa(c->stream, rtr::PackedXyz{c->pk_hdr, c->pk_planes}, c->n, c->x, c->y, c->z);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, RTR_ERR_HIP, "unpack launch failed: %s", hipGetErrorString(e));
+    return RTR_OK;
+}
+void drop_soa(rtr_ctx *c) {  // after the cloud has been packed: 12 B per point back
+    if (!c->pk_hdr || c->opt_keep_soa || !c->x) return;
+    (void)sync_streams(c);
+    dfree(c->x); dfree(c->y); dfree(c->z);
 }
 
 int alloc_cloud(rtr_ctx *c, uint64_t n) {
@@ -348,8 +402,19 @@ int alloc_cloud(rtr_ctx *c, uint64_t n) {
         HIP_TRY(c, hipMalloc((void **)&c->spread, ((n_pad / 4 + 63) / 64) * sizeof(float)));
         c->cap = n_pad;
     }
+    if (!c->x) {  // (the previous cloud was resident in packed form only)
+        HIP_TRY(c, hipMalloc((void **)&c->x, c->cap * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->y, c->cap * 4));
+        HIP_TRY(c, hipMalloc((void **)&c->z, c->cap * 4));
+    }
+    if (n != c->n) {  // (the adaptive extent pool starts over)
+        c->pool_worst = false;
+        c->entries_max = 0;
+        if (c->entries_host) *c->entries_host = 0u;
+    }
     c->n = n;
     c->list_valid = false;
+    c->last_valid = false;
     c->split_cooldown = kSplitCooldown;  // (a new cloud: nothing is known about its frames)
     return RTR_OK;
 }
@@ -404,10 +469,23 @@ hipError_t sync_streams(rtr_ctx *c) {
 // Tile-store errors (entries dropped by T1: an extent that never appeared, an exhausted extent pool) reach the
 // host through a mapped word that T1's epilogue writes; every call that has just synchronised reports and
 // clears it -- a wrong frame is never returned as RTR_OK.
-int check_store_error(rtr_ctx *c) {
+// retry (out): the only error is an overflow of the ADAPTIVE extent pool (ensure_lists) -- the pool is worst-case sized
+// from now on and the caller renders the frame again instead of failing.
+int check_store_error(rtr_ctx *c, bool *retry = nullptr) {
+    if (retry) *retry = false;
     if (!c->err_host) return RTR_OK;
     const uint32_t e = __atomic_exchange_n(c->err_host, 0u, __ATOMIC_ACQUIRE);
     if (e == 0u) return RTR_OK;
+    if (e == 2u && c->opt_debug_dyn_cap < 0 && c->F().dyn_cap < pool_worst_cap(c)) {
+        c->pool_worst = true;  // (ensure_lists re-allocates before the next T1)
+        if (retry) {
+            *retry = true;
+            return RTR_OK;
+        }
+        return fail(c, RTR_ERR_INTERNAL, "tile store error 0x2: the extent pool, sized by the frames seen so far, was too small "
+                    "for a frame rendered since the last synchronising call -- entries were dropped; the pool is worst-case "
+                    "sized from now on: render the frame again (option pool_worst_case = 1 sizes it so from the start)");
+    }
     return fail(c, RTR_ERR_INTERNAL, "tile store error 0x%x: %s%s%s%s-- entries were dropped, frames rendered since the last "
                 "synchronising call are incomplete", e, (e & 1u) ? "a stream extent never appeared " : "",
                 (e & 2u) ? "the dynamic extent pool overflowed " : "",
@@ -530,11 +608,19 @@ int rtr_create(rtr_ctx **out, int device) {
         c->split_dev = static_cast<uint32_t *>(d);
         c->split_cooldown = kSplitCooldown;
     }
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->entries_host, sizeof(uint32_t), hipHostMallocMapped);
+    if (e == hipSuccess) {
+        *c->entries_host = 0u;
+        void *d = nullptr;
+        e = hipHostGetDevicePointer(&d, c->entries_host, 0);
+        c->entries_dev = static_cast<uint32_t *>(d);
+    }
     if (e != hipSuccess) {
         int rc = fail(nullptr, RTR_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
         if (c->minmax) (void)hipFree(c->minmax);
         if (c->err_host) (void)hipHostFree(c->err_host);
         if (c->split_host) (void)hipHostFree(c->split_host);
+        if (c->entries_host) (void)hipHostFree(c->entries_host);
         (void)hipStreamDestroy(c->own_stream);
         delete c;
         return rc;
@@ -556,6 +642,7 @@ int rtr_destroy(rtr_ctx *c) {
     if (c->p2p.status_host) (void)hipHostFree(c->p2p.status_host);
     if (c->split_host) (void)hipHostFree(c->split_host);
     if (c->err_host) (void)hipHostFree(c->err_host);
+    if (c->entries_host) (void)hipHostFree(c->entries_host);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -721,7 +808,22 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
         c->opt_pack = value;
         DevGuard g(c->device);
         HIP_TRY(c, sync_streams(c));
-        return pack_cloud(c);
+        if (c->n == 0 || c->cap == 0) return RTR_OK;
+        if (int rc = ensure_soa(c)) return rc;  // (packing reads the fp32 arrays; "pack" = 0 leaves them as the resident form)
+        if (int rc = pack_cloud(c)) return rc;
+        drop_soa(c);
+        return RTR_OK;
+    }
+    if (!strcmp(key, "keep_soa")) {  // 1: the fp32 SoA arrays stay resident beside the packed form (12 B per point)
+        c->opt_keep_soa = value != 0;
+        DevGuard g(c->device);
+        if (c->opt_keep_soa) return (c->cap && c->n) ? ensure_soa(c) : RTR_OK;
+        drop_soa(c);
+        return RTR_OK;
+    }
+    if (!strcmp(key, "pool_worst_case")) {  // 1: the extent pool is sized for the worst case (2 n entries) at once
+        c->opt_pool_worst = value != 0;
+        return RTR_OK;
     }
     if (!strcmp(key, "probe_variant")) {
         c->opt_probe = value;
@@ -752,6 +854,21 @@ int rtr_get_option(rtr_ctx *c, const char *key, int *value) {
     else if (!strcmp(key, "lane_test")) *value = c->opt_lane_test;
     else if (!strcmp(key, "lean")) *value = c->opt_lean;
     else if (!strcmp(key, "p2p_open")) *value = c->p2p.open ? 1 : 0;  // the peers' buffers are mapped (rtr_p2p_open)
+    else if (!strcmp(key, "keep_soa")) *value = c->opt_keep_soa;
+    else if (!strcmp(key, "pool_worst_case")) *value = c->opt_pool_worst;
+    else if (!strcmp(key, "resident_millibytes_per_point")) {
+        // device memory this context holds for the cloud and its frames, per point: coordinates (fp32 SoA and / or packed
+        // form), colours, chunk boxes and lane spreads, tile stores and extent pools, frame buffers
+        const uint64_t nchunks = ((c->cap / 4) + 63) / 64;
+        uint64_t b = (c->x ? 12 * c->cap : 0) + (c->rgba ? 4 * c->cap : 0) + nchunks * 28 + (c->pk_hdr ? c->pk_bytes + 64 : 0);
+        for (const auto &f : c->fs) {
+            b += f.dyn ? f.dyn_cap * 8 : 0;
+            b += f.store.ext0 ? ((uint64_t)f.nst * rtr::kS0 + 16) * 8 + rtr::ts_meta_words(f.nst, f.ntiles) * 4 : 0;
+        }
+        const uint64_t npix = (uint64_t)c->W * c->H;
+        b += c->depth ? npix * (4 + 16 + 3 + 1 + 10) : 0;
+        *value = c->n ? (int)((b * 1000) / c->n > 0x7FFFFFFFull ? 0x7FFFFFFF : (b * 1000) / c->n) : 0;
+    }
     else if (!strcmp(key, "pack")) *value = c->opt_pack;
     else if (!strcmp(key, "packed")) *value = c->pk_hdr ? 1 : 0;  // the point kernel reads the packed coordinates
     else if (!strcmp(key, "packed_millibytes_per_point"))         // its coordinate stream, headers included (12000 = raw)
@@ -769,6 +886,7 @@ int rtr_stream_probe(rtr_ctx *c, const float P[16]) {
     NEED(c, P != nullptr, "P is NULL");
     if (int rc = check_frame(c)) return rc;
     DevGuard g(c->device);
+    if (int rc = ensure_soa(c)) return rc;
     { Timed t(c, RTR_K_PROBE); rtr::launch_stream_probe(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->minmax, c->opt_probe); }
     return launch_check(c, "stream_probe");
 }
@@ -797,11 +915,28 @@ int rtr_reset_stream(rtr_ctx *c) {
     return switch_stream(c, c->masked_tail ? c->masked_tail : c->own_stream);
 }
 
+// After a synchronisation: tile-store errors.  When the adaptive extent pool overflowed and the last frame was a whole
+// one (rtr_render and what is built on it), that frame is rendered again with the grown pool -- the device buffers hold
+// the right frame when the call returns.
+static int finish_sync_rerender(rtr_ctx *c) {
+    float P[16];
+    memcpy(P, c->last_P, sizeof P);
+    return rtr_render(c, P, c->last_filter);
+}
+static int finish_sync(rtr_ctx *c) {
+    bool retry = false;
+    int rc = check_store_error(c, c->last_valid ? &retry : nullptr);
+    if (rc || !retry) return rc;
+    if ((rc = finish_sync_rerender(c))) return rc;
+    HIP_TRY(c, sync_streams(c));
+    return check_store_error(c);
+}
+
 int rtr_synchronize(rtr_ctx *c) {
     if (!c) return RTR_ERR_INVALID;
     DevGuard g(c->device);
     HIP_TRY(c, sync_streams(c));
-    return check_store_error(c);
+    return finish_sync(c);
 }
 
 // ---- cloud -------------------------------------------------------------------------
@@ -923,7 +1058,10 @@ int rtr_upload_points(rtr_ctx *c, const float *xyz, size_t xs, const uint8_t *rg
     if (int rc2 = launch_check(c, "aos_to_soa")) return rc2;
     free_pack(c);
     if (int rc2 = auto_reorder(c)) return rc2;
-    return c->pk_hdr ? RTR_OK : pack_cloud(c);  // (a sort has packed already)
+    if (!c->pk_hdr)  // (a sort has packed already)
+        if (int rc2 = pack_cloud(c)) return rc2;
+    drop_soa(c);
+    return RTR_OK;
 }
 
 int rtr_generate_synthetic(rtr_ctx *c, int scene, uint64_t seed, uint64_t first, uint64_t count, uint64_t total) {
@@ -943,7 +1081,10 @@ int rtr_generate_synthetic(rtr_ctx *c, int scene, uint64_t seed, uint64_t first,
     if (int rc2 = launch_check(c, "generate")) return rc2;
     free_pack(c);
     if (int rc2 = auto_reorder(c)) return rc2;
-    return c->pk_hdr ? RTR_OK : pack_cloud(c);
+    if (!c->pk_hdr)
+        if (int rc2 = pack_cloud(c)) return rc2;
+    drop_soa(c);
+    return RTR_OK;
 }
 
 int rtr_reorder_points(rtr_ctx *c) {
@@ -951,6 +1092,7 @@ int rtr_reorder_points(rtr_ctx *c) {
     DevGuard g(c->device);
     HIP_TRY(c, sync_streams(c));
     c->list_valid = false;
+    if (int rc = ensure_soa(c)) return rc;
     int e = rtr::reorder_morton(c->stream, c->x, c->y, c->z, c->rgba, c->n);
     if (e != 0) return fail(c, RTR_ERR_HIP, "reorder failed: %s", hipGetErrorString((hipError_t)e));
     c->reordered = true;
@@ -958,7 +1100,9 @@ int rtr_reorder_points(rtr_ctx *c) {
     rtr::launch_chunk_bounds(c->stream, cloud_of(c), c->bounds, c->spread);
     HIP_TRY(c, sync_streams(c));
     if (int rc = launch_check(c, "reorder")) return rc;
-    return pack_cloud(c);
+    if (int rc = pack_cloud(c)) return rc;
+    drop_soa(c);
+    return RTR_OK;
 }
 
 int rtr_num_points(const rtr_ctx *c, uint64_t *n) {
@@ -973,6 +1117,7 @@ int rtr_download_points(rtr_ctx *c, float *xyzw, uint8_t *rgba, uint64_t first, 
     NEED(c, first + count <= c->n, "range exceeds the resident cloud");
     if (count == 0) return RTR_OK;
     DevGuard g(c->device);
+    if (int rc = ensure_soa(c)) return rc;  // (a cloud resident in packed form only is decoded for the copy, bit for bit)
     const uint64_t chunk = 1ull << 24;
     uint64_t m = count < chunk ? count : chunk;
     struct Staging {  // freed on every exit path
@@ -991,6 +1136,7 @@ int rtr_download_points(rtr_ctx *c, float *xyzw, uint8_t *rgba, uint64_t first, 
         HIP_TRY(c, hipMemcpyAsync(rgba + off * 4, dc, cnt * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, sync_streams(c));
     }
+    drop_soa(c);
     return launch_check(c, "soa_to_aos");
 }
 
@@ -1108,6 +1254,7 @@ int rtr_min_depth_pass(rtr_ctx *c, const float P[16]) {
     if (int rc = check_frame(c)) return rc;
     DevGuard g(c->device);
     c->list_valid = false;
+    c->last_valid = false;
     if (use_tiles(c)) {
         if (int rc = bin_points(c, P, false, c->p2p.whole_frame)) return rc;
         Timed t(c, RTR_K_TILE);
@@ -1115,6 +1262,7 @@ int rtr_min_depth_pass(rtr_ctx *c, const float P[16]) {
                          (c->p2p.whole_frame ? 6 : 0) | (c->lean_parity << 4), nullptr);  // 2: only writer, 4: tiles without entries are not written
         mark_consumed(c);
     } else {
+        if (int rc = ensure_soa(c)) return rc;
         Timed t(c, RTR_K_MIN_DEPTH);
         rtr::launch_min_depth(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->depth);
     }
@@ -1159,6 +1307,7 @@ int rtr_accumulate_pass(rtr_ctx *c, const float P[16]) {
                          c->p2p.whole_frame ? 6 : 0, pyr.enable ? &pyr : nullptr, (dsl.chunk || dsl.peers) ? &dsl : nullptr);
         mark_consumed(c);
     } else {
+        if (int rc = ensure_soa(c)) return rc;
         Timed t(c, RTR_K_ACCUMULATE);
         rtr::launch_accumulate(c->stream, cloud_of(c), make_proj(P), c->W, c->H, c->depth, c->acc, c->prm.depth_window);
     }
@@ -1260,6 +1409,9 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
         }
         mark_consumed(c);
         if ((rc = launch_check(c, "tile frame"))) return rc;
+        memcpy(c->last_P, P, sizeof c->last_P);  // (what a synchronising call repeats if the adaptive pool overflowed)
+        c->last_filter = with_filter;
+        c->last_valid = true;
         if (with_filter) return filter_impl(c, pyr.enable ? rtr::tile_count(c->W, c->H) : 0);
         return RTR_OK;
     } else {
@@ -1278,14 +1430,18 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
 static int frame_to_host(rtr_ctx *c, const float P[16], uint8_t *host_img, float *host_depth, int with_filter) {
     if (!c) return RTR_ERR_INVALID;
     if (!host_img && !host_depth) return fail(c, RTR_ERR_NO_OUTPUT, "both outputs are NULL (project_cloud.cu:270-273)");
-    int rc = rtr_render(c, P, with_filter);
-    if (rc) return rc;
-    DevGuard g(c->device);
-    size_t npix = (size_t)c->W * c->H;
-    if (host_depth) HIP_TRY(c, hipMemcpyAsync(host_depth, c->depth, npix * 4, hipMemcpyDeviceToHost, c->stream));
-    if (host_img) HIP_TRY(c, hipMemcpyAsync(host_img, c->img, npix * 3, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, sync_streams(c));
-    return check_store_error(c);
+    for (int attempt = 0;; ++attempt) {  // (a second time only after the adaptive extent pool overflowed: check_store_error)
+        int rc = rtr_render(c, P, with_filter);
+        if (rc) return rc;
+        DevGuard g(c->device);
+        size_t npix = (size_t)c->W * c->H;
+        if (host_depth) HIP_TRY(c, hipMemcpyAsync(host_depth, c->depth, npix * 4, hipMemcpyDeviceToHost, c->stream));
+        if (host_img) HIP_TRY(c, hipMemcpyAsync(host_img, c->img, npix * 3, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, sync_streams(c));
+        bool retry = false;
+        rc = check_store_error(c, attempt == 0 ? &retry : nullptr);
+        if (rc || !retry) return rc;
+    }
 }
 
 int rtr_project(rtr_ctx *c, const float P[16], uint8_t *host_img, float *host_depth) {
@@ -1396,8 +1552,10 @@ int rtr_p2p_export(rtr_ctx *c, rtr_p2p_handles *mine) {
     NEED(c, !c->opt_overlap, "the peer-to-peer exchange needs option overlap off (the peers map ONE tile store)");
     DevGuard g(c->device);
     HIP_TRY(c, sync_streams(c));
-    // (the owner-computes form reads the peers' tile stores: allocate this rank's now -- it is sized by the cloud)
+    // (the owner-computes form reads the peers' tile stores: allocate this rank's now -- it is sized by the cloud, for
+    // the worst case: a pool the peers have mapped must never move)
     c->cur = 0;
+    c->pool_worst = true;
     if (int rc = ensure_lists(c)) return rc;
     if (int rc = ensure_tiles(c, c->stream)) return rc;
     if (int rc = p2p_alloc(c)) return rc;
@@ -1672,6 +1830,12 @@ int rtr_download_buffer(rtr_ctx *c, int which, void *host, size_t bytes) {
     if (rc) return rc;
     NEED(c, bytes == b, "size mismatch");
     DevGuard g(c->device);
+    HIP_TRY(c, hipMemcpyAsync(host, p, b, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, sync_streams(c));
+    bool retry = false;
+    rc = check_store_error(c, c->last_valid ? &retry : nullptr);
+    if (rc || !retry) return rc;
+    if ((rc = finish_sync_rerender(c))) return rc;  // (the adaptive extent pool overflowed: the frame again, then the copy)
     HIP_TRY(c, hipMemcpyAsync(host, p, b, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, sync_streams(c));
     return check_store_error(c);

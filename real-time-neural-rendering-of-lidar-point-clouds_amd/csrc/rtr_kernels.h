@@ -116,6 +116,7 @@ struct StoreConsts {  // rarely needed, rarely changing: lives in the store's he
     uint32_t heavy, slice;        // split tiles with more entries than `heavy` into slices of >= `slice`
     uint32_t *err_host;           // mapped host word: T1's epilogue ORs a frame's tile-store error code into it
     uint32_t *split_host;         // mapped host word: tiles above the split threshold in the frame T1 has just binned
+    uint32_t *entries_host;       // mapped host word: in-frustum entries of the last frame whose statistics are complete
 };
 // meta, in 32-bit words:
 //   fill[nst << kFillShiftMax]  stream length while T1 runs; zero between frames
@@ -209,10 +210,10 @@ __host__ __device__ inline unsigned long long *ts_dir(const TileStore &S) {
 // overflowed -- entries were dropped), published by T1's epilogue from kHdrErrLive, which store_error() ORs into
 // while T1 runs; kHdrColourChunks: 256-point chunks with at least one in-frustum point (each loads 1 KiB of colours)
 enum { kHdrItems = 0, kHdrSplitItems = 1, kHdrEntries = 2, kHdrHeaviest = 3, kHdrSlice = 4, kHdrError = 5,
-       kHdrSplitTiles = 6, kHdrColourChunks = 7, kHdrConsts = 8, kHdrErrLive = 24,
+       kHdrSplitTiles = 6, kHdrColourChunks = 7, kHdrConsts = 8, kHdrErrLive = 28,
        // k_tile_split: slice records taken in its min phase, slices whose minima are in the depth buffer, records taken
        // in its second phase
-       kHdrSplitQ1 = 25, kHdrSplitDone = 26, kHdrSplitQ2 = 27 };
+       kHdrSplitQ1 = 29, kHdrSplitDone = 30, kHdrSplitQ2 = 31 };
 static_assert(kHdrConsts + sizeof(StoreConsts) / 4 <= kHdrErrLive, "StoreConsts overlaps the header words behind it");
 __host__ __device__ inline const StoreConsts *ts_consts(const TileStore &S) {
     return reinterpret_cast<const StoreConsts *>(ts_hdr(S) + kHdrConsts);
@@ -243,6 +244,8 @@ void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds, float *sp
 void pack_measure(hipStream_t s, const Cloud &c, uint4 *hdr, uint32_t *chunk_planes, uint64_t *total_planes);  // (c.spread -> hdr[2 c + 1].z)
 void pack_write(hipStream_t s, const Cloud &c, const uint4 *hdr, uint32_t *planes);
 void pack_verify(hipStream_t s, const Cloud &c, const uint4 *hdr, const uint32_t *planes, uint64_t *mismatches);
+// x, y, z (padded to a multiple of 4 points) back from the packed form, bit for bit
+void unpack_to_soa(hipStream_t s, const PackedXyz &pk, uint64_t n, float *x, float *y, float *z);
 int reorder_morton(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, uint64_t n);  // rtr_reorder.hip
 // mean diagonal of the 256-point chunk boxes / diagonal of the cloud's box, from launch_chunk_bounds' output
 // absmax[3]: the largest finite |x|, |y|, |z| over the chunk boxes (+inf when no chunk has a finite box)

@@ -675,6 +675,7 @@ __device__ void bin_epilogue(const TileStore &S, int W, int H, int flags, uint32
         hdr[kHdrItems] = (uint32_t)g.ntiles - n_heavy + n_split_items;
         hdr[kHdrSplitItems] = n_split_items;
         hdr[kHdrEntries] = total;
+        if (sc.entries_host) *(volatile gu32_t)sc.entries_host = total;  // (the host sizes the extent pool by it)
         hdr[kHdrHeaviest] = mx;
         hdr[kHdrSlice] = slice;
         hdr[kHdrSplitTiles] = n_heavy;
@@ -809,6 +810,7 @@ __device__ void lean_fold(const TileStore &S, int q, uint32_t *s_w /*[24]*/) {
         hdr[kHdrSplitTiles] = 0u;  // (a lean frame splits nothing: tiles above the threshold were done by one workgroup each)
         typedef uint32_t __attribute__((address_space(1))) *gu32_t;
         if (sc->split_host) *(volatile gu32_t)sc->split_host = over ? 1u : 0u;  // ... and reported: the split launch comes back
+        if (sc->entries_host) *(volatile gu32_t)sc->entries_host = sum;
         *flag = 0u;
     }
 }
@@ -979,8 +981,11 @@ __device__ __forceinline__ void unpack_chunk(const ChunkRaw &c, uint32_t widths,
 // lz / lall the L1 norms of the rows involved (host: lane_test_consts).  The margin step transfers a bound from p_0 to
 // p_k through REAL arithmetic, while the exact test of p_k runs on its ROUNDED rows: the rows' rounding errors
 // (<= 4 x 2^-24 of their term magnitudes each) must stay below the margins' 0.25 px = 0.25 r.z, hence it is only applied
-// when every point of the lane has r.z > zsafe = 2^-17 x (bound of the rows' term magnitudes over the cloud's
-// bounding box) -- ~0.1-0.3 m for a room and a 1080p camera; nearer lanes just stay candidates.  A chunk with any
+// when every point of the lane has r.z > zsafe.  (A point the exact test accepts has r.x >= -0.5 r.z (1 + 3u), u = 2^-24,
+// i.e. M >= 0.25 r.z in its rounded rows; each row errs by <= 4 u T from the real one, T the sum of its term magnitudes,
+// so M(p_0) as computed is >= 0.25 r.z(p_k) - lall s - 8 u (Tx + (W + 0.25) Tz): a wrong rejection needs
+// r.z(p_k) < 32 u (Tx + (W + 0.25) Tz) = 2^-19 (...); zsafe = 2^-18 x that bound over the cloud's bounding box, twice
+// what is needed -- ~0.15 m for a room and a 1080p camera.)  Nearer lanes just stay candidates.  A chunk with any
 // candidate lane takes the full path below (all four points per lane, the exact arithmetic decides as before), so
 // frames stay bit-identical; chunks with a non-finite or huge coordinate carry s = +inf and always take it.
 struct LaneTest {
@@ -996,7 +1001,7 @@ static LaneTest lane_test_consts(const Proj &P, int W, int H, const float absmax
     t.lall = ((l1x > l1y ? l1x : l1y) + hi * l1z) * 1.001f;
     auto mag = [&](int r) { return fabsf(m[4 * r]) * absmax[0] + fabsf(m[4 * r + 1]) * absmax[1] + fabsf(m[4 * r + 2]) * absmax[2] + fabsf(m[4 * r + 3]); };
     const float rx = mag(0), ry = mag(1), rz = mag(2);
-    t.zsafe = 0x1p-17f * ((rx > ry ? rx : ry) + hi * rz);
+    t.zsafe = 0x1p-18f * ((rx > ry ? rx : ry) + hi * rz);
     if (!(t.zsafe >= 1e-30f)) t.zsafe = __builtin_inff();  // (NaN / no finite box: the margin step never applies)
     if (!(t.lz < 3e38f) || !(t.lall < 3e38f)) t.zsafe = __builtin_inff(), t.lz = t.lall = 3e38f;
     return t;
@@ -1094,6 +1099,10 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
         return __uint_as_float(x);
     };
     uint32_t n_colour = 0;  // chunks of this wave whose colours were loaded (frame statistics)
+    // (Skipping the per-point conservative test below for chunks that have been through the lane test -- inside a stretch
+    // of the cloud that lies in the frustum nearly every point passes it -- was measured: 135-142 us against 122-124.  A
+    // chunk near the camera plane stays a candidate of the lane test, whose margin step needs r.z > zsafe, and it is this
+    // per-point test that lets such a chunk go before the exact arithmetic.)
     auto do_quad = [&](uint32_t i, bool live, const Rows &r) {
         const float *rz = r.rz;
         // (one max3 + max + compare instead of four compares and their combination; fmaxf skips NaNs, and an
@@ -1931,9 +1940,12 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
                 const unsigned long long a = cnt * sub / nsub, b = cnt * (sub + 1u) / nsub;
                 const unsigned long long e_hi = (unsigned long long)kS0 << k;
                 const unsigned long long lo = a > e_lo ? a : e_lo, hi = b < e_hi ? b : e_hi;
-                if (hi > lo) {
-                    const uint64_t *p = k == 0 ? S.ext0 + ((size_t)st << kS0Shift) + lo
-                                               : ts_consts(S)->dyn + (ts_dir(S)[(size_t)st * kDirK + k] >> 24) + (lo - e_lo);
+                // (an extent that was never handed out in this frame, or that lies beyond the pool -- the adaptive pool
+                // overflowed, T1 has dropped its entries and flagged the frame -- is not read: the frame is repeated)
+                const unsigned long long de = k == 0 ? 0ull : ts_dir(S)[(size_t)st * kDirK + k];
+                const bool there = k == 0 || ((uint32_t)(de & 0xFFFFFFull) == S.seq && (de >> 24) + e_lo <= ts_consts(S)->dyn_cap);
+                if (hi > lo && there) {
+                    const uint64_t *p = k == 0 ? S.ext0 + ((size_t)st << kS0Shift) + lo : ts_consts(S)->dyn + (de >> 24) + (lo - e_lo);
                     const uint32_t q = atomicAdd(&s_nseg, 1u);
                     s_seg_p[q] = (unsigned long long)p;
                     s_seg_n[q] = (uint32_t)(hi - lo);
@@ -2677,6 +2689,23 @@ __global__ __launch_bounds__(kBlock) void k_pack_verify(const uint4 *__restrict_
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// the SoA arrays back from the packed form (bit for bit: the form is lossless) -- for the calls that read fp32
+// coordinates when the context keeps only the packed form resident (rtr_api.hip, ensure_soa)
+__global__ __launch_bounds__(kBlock) void k_unpack_soa(const uint4 *__restrict__ hdr, const uint32_t *__restrict__ planes,
+                                                       uint64_t n4, float4 *__restrict__ x4, float4 *__restrict__ y4,
+                                                       float4 *__restrict__ z4) {
+    const uint64_t nchunks = (n4 + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t c = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6; c < nchunks; c += ((uint64_t)gridDim.x * kBlock) >> 6) {
+        const uint4 h0 = hdr[2 * c], h1 = hdr[2 * c + 1];
+        const ChunkRaw raw = load_chunk(planes, h0, h1, lane);
+        float4 X, Y, Z;
+        unpack_chunk(raw, h0.w, h0.x, h0.y, h0.z, X, Y, Z, lane);
+        const uint64_t i = c * 64 + lane;
+        if (i < n4) x4[i] = X, y4[i] = Y, z4[i] = Z;
+    }
+}
+
 static unsigned pack_grid(uint64_t n4) {
     const uint64_t blocks = ((n4 + 63) / 64 + 3) / 4;
     return (unsigned)(blocks < 8192 ? (blocks ? blocks : 1) : 8192);
@@ -2699,6 +2728,12 @@ void pack_verify(hipStream_t s, const Cloud &c, const uint4 *hdr, const uint32_t
     if (n4 == 0) return;
     hipLaunchKernelGGL(k_pack_verify, dim3(pack_grid(n4)), dim3(kBlock), 0, s, (const uint4 *)c.x, (const uint4 *)c.y,
                        (const uint4 *)c.z, n4, hdr, planes, (unsigned long long *)mismatches);
+}
+
+void unpack_to_soa(hipStream_t s, const PackedXyz &pk, uint64_t n, float *x, float *y, float *z) {
+    const uint64_t n4 = (n + 3) / 4;
+    if (n4 == 0) return;
+    hipLaunchKernelGGL(k_unpack_soa, dim3(pack_grid(n4)), dim3(kBlock), 0, s, pk.hdr, pk.planes, n4, (float4 *)x, (float4 *)y, (float4 *)z);
 }
 
 void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, float window, uint32_t *depth,

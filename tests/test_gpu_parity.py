@@ -869,3 +869,56 @@ def test_lean_frames_match_the_epilogue_form(pkg, orc, projector):
     projector.upload_points(np.zeros((0, 4), np.float32), np.zeros((0, 4), np.uint8))
     img, depth = projector.project(P4)
     assert (depth.view(np.uint32) == 0x7F7FFFFF).all() and not img.any()
+
+
+def test_packed_only_residency_and_the_adaptive_extent_pool(pkg, orc, projector):
+    """Footprint (option keep_soa = 0, pool_worst_case = 0: the defaults).  A packed cloud keeps no fp32 SoA arrays: the
+    calls that read fp32 coordinates decode them again, bit for bit (rtr_download_points, mode 0, the sort, pack = 0).
+    The extent pool is sized by the frames seen; a frame that overflows it (every point in ONE tile stream right after
+    upload) is rendered again by the synchronising call -- the caller sees the right frame and RTR_OK."""
+    n, W, H = 2_000_000, 640, 480
+    xyzw, rgba = orc.generate("room_shell", 0xC0FFEE09, 0, n, n)
+    projector.upload_points(xyzw, rgba)
+    projector.set_resolution(W, H)
+    assert projector.get_option("packed") == 1 and projector.get_option("keep_soa") == 0
+    small = projector.get_option("resident_millibytes_per_point")
+    P = pkg.orbit_projection(7, W, H)
+    ref = orc.project(xyzw, rgba, P, W, H)
+    img, depth = projector.project(P)
+    assert np.array_equal(depth.view(np.uint32), ref["depth_bits"]) and np.array_equal(img, ref["img"])
+    back, cols = projector.download_points()           # decoded from the packed form
+    assert np.array_equal(back.view(np.uint32), xyzw.view(np.uint32)) and np.array_equal(cols, rgba)
+    projector.set_option("mode", 0)                     # the atomic form reads fp32 coordinates
+    img, depth = projector.project(P)
+    assert np.array_equal(depth.view(np.uint32), ref["depth_bits"]) and np.array_equal(img, ref["img"])
+    projector.set_option("mode", 1)
+    projector.set_option("pack", 0)                     # fp32 becomes the resident form ...
+    img, depth = projector.project(P)
+    assert np.array_equal(depth.view(np.uint32), ref["depth_bits"]) and np.array_equal(img, ref["img"])
+    projector.set_option("pack", 1)                     # ... and the packed one again
+    assert projector.get_option("packed") == 1
+    packed_only = projector.get_option("resident_millibytes_per_point")  # (the extent pool has grown with the frames seen)
+    assert small > 0 and packed_only > 0
+    projector.set_option("keep_soa", 1)
+    assert projector.get_option("resident_millibytes_per_point") >= packed_only + 11_900
+    projector.set_option("keep_soa", 0)
+    assert projector.get_option("resident_millibytes_per_point") == packed_only
+    projector.reorder_points()
+    img, depth = projector.project(P, filtered=True)
+    rf = orc.filter(ref["depth_bits"], ref["img"])
+    assert np.array_equal(depth.view(np.uint32), rf["depth"].view(np.uint32)) and np.array_equal(img, rf["img"])
+    # the adaptive pool: n / 4 entries for a fresh cloud; the whole cloud inside one 32x16 tile needs ~2 n
+    K = np.array([[1.0, 0, 8.0], [0, 1.0, 8.0], [0, 0, 1]])   # focal length 1 px: everything within a pixel of (8, 8)
+    E = np.eye(4)
+    E[2, 3] = 20.0
+    P_one = orc.compose_projection(K, E)
+    ref1 = orc.project(xyzw, rgba, P_one, W, H)
+    assert orc.envelope_points(xyzw, P_one, W, H, 0, 0)["accepted"] == n and (ref1["depth_bits"] != 0x7F7FFFFF).sum() <= 9
+    img, depth = projector.project(P_one)               # overflows, is repeated inside the call
+    assert np.array_equal(depth.view(np.uint32), ref1["depth_bits"]) and np.array_equal(img, ref1["img"])
+    assert projector.frame_stats()["errors"] == 0
+    projector.upload_points(xyzw, rgba)                 # a new cloud: adaptive again; this time through render + synchronize
+    projector.render(P_one, False)
+    projector.synchronize()
+    assert np.array_equal(projector.download(pkg._lib.BUF_DEPTH), ref1["depth_bits"])
+    assert np.array_equal(projector.download(pkg._lib.BUF_IMAGE), ref1["img"])
