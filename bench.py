@@ -73,7 +73,7 @@ def parse():
     ap.add_argument("--time-every", type=int, default=-1, choices=[-1, 0, 1, 2, 4],
                     help="bracket the dominant kernel on every frame (1), every 2nd (2), every 4th frame (4) or never "
                          "(0: no roofline object; to measure what the bracketing itself costs).  Default: every 4th "
-                         "frame, every 2nd for runs of <= 32 steps (so that a 20-step run still times 10 launches).  A "
+                         "frame, every 2nd for runs of <= 12 steps (a 20-step run times 5 launches).  A "
                          "bracketed dispatch costs ~10 us of stream time (completion signal + time stamps): 0.228 ms "
                          "per frame with every frame bracketed, 0.217 with every 4th")
     ap.add_argument("--time-all-kernels", action="store_true",
@@ -235,7 +235,7 @@ def main():
     W, H = args.width, args.height
     with_filter = not args.no_filter
     poses = [pkg.orbit_projection(k, W, H) for k in range(args.warmup + args.steps)]
-    every = args.time_every if args.time_every >= 0 else (2 if args.steps <= 32 else 4)
+    every = args.time_every if args.time_every >= 0 else (2 if args.steps <= 12 else 4)
     depth_k = args.pipeline if multi else args.frames_in_flight
 
     def all_ranks(ok):

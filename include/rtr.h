@@ -122,7 +122,7 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          coordinates (mode 0 and the phase calls with another matrix, rtr_reorder_points, rtr_download_points,
  *          option "pack" = 0); 1 = they stay resident beside the packed form.
  *  "pool_worst_case": 0 (default) = the pool of dynamic stream extents is sized by the frames the cloud has had (8 x the
- *          most in-frustum entries a completed frame reported, at least n / 4: 2 B per point instead of 16).  A frame
+ *          most in-frustum entries a completed frame reported, at least n / 2: 4 B per point instead of 16).  A frame
  *          whose entries jump past that overflows it; the next synchronising call (every call that copies results to the
  *          host, rtr_synchronize, rtr_download_buffer) then sizes the pool for the worst case and renders that frame
  *          again before it returns -- transparent, except for whoever consumes frames on the stream without ever

@@ -335,7 +335,8 @@ int ensure_tiles(rtr_ctx *c, hipStream_t s) {
 // rtr_kernels.h), and a frame has at most n entries: 2 n + 64 entries = 16 B per point is the worst case (round 1's
 // wave lists + sorted copy: 24).  An ordinary view has a few per cent of the cloud inside the frustum, so the pool is
 // sized by the frames this cloud has had: 8 x the most entries a completed frame reported (a mapped host word, read
-// without a sync), at least n / 4 and 2^20 -- 2 B per point.  A frame whose entries jump past that (the camera suddenly
+// without a sync), at least n / 2 and 2^20 -- 4 B per point (n / 4 re-allocated in the middle of BASELINE C2's frames:
+// a sync, a free and a malloc cost more than the memory is worth).  A frame whose entries jump past that (the camera suddenly
 // sees four times more of the cloud than ever before) overflows the pool, reports it (tile-store error 2), and the next
 // synchronising call grows the pool to the worst case and renders the frame again (finish_sync) -- the caller never
 // sees it, unless it consumes frames on the stream without ever synchronising: option "pool_worst_case" is for that.
@@ -348,7 +349,7 @@ uint64_t pool_want_cap(rtr_ctx *c, uint64_t have) {
         const uint64_t e = __atomic_load_n(c->entries_host, __ATOMIC_RELAXED);
         if (e > c->entries_max) c->entries_max = e;
     }
-    uint64_t floor_ = c->n / 4 > (1ull << 20) ? c->n / 4 : (1ull << 20);
+    uint64_t floor_ = c->n / 2 > (1ull << 20) ? c->n / 2 : (1ull << 20);
     // (hysteresis: grown to 8 x when the head-room over the densest frame seen falls under 4 x)
     uint64_t want = have >= 4 * c->entries_max && have >= floor_ ? have : (8 * c->entries_max > floor_ ? 8 * c->entries_max : floor_);
     return want < worst ? want : worst;

@@ -368,9 +368,6 @@ constexpr int kTileThreadsCompact = RTR_TILE0_THREADS;  // k_tile<0> (see tile_b
 #define RTR_TILE0_BATCH 8
 #endif
 constexpr int kTileBatch = RTR_TILE_BATCH;    // entries in flight per thread in k_tile
-#ifndef RTR_T1_PAIRS
-#define RTR_T1_PAIRS 0  // 1: the packed point kernel handles two chunks per iteration (measured slower, see k_project_bin)
-#endif
 #ifndef RTR_T1_WAVES
 #define RTR_T1_WAVES 5  // the packed point kernel: five waves per SIMD (96 registers, four of them spilled to scratch in the
 #endif                  // long path only; round 4: 126-129 us against 127-133 at four, six -- 80 registers, 51 spilled -- 180);
@@ -869,14 +866,6 @@ __device__ __forceinline__ AxisRaw ld_axis(const uint8_t *block, uint32_t b, int
     const u32x4_a4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4 *>(block + 4u * dw));
     return AxisRaw{{v.x, v.y, v.z, v.w}};
 }
-// the first 8 of those 16 bytes: all of the lane's FIRST value (shift <= 28, b <= 25) -- what T1's lane test reads
-typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
-struct AxisLo { uint32_t d[2]; };
-__device__ __forceinline__ AxisLo ld_axis_lo(const uint8_t *block, uint32_t b, int lane) {
-    const uint32_t dw = (b * (uint32_t)lane) >> 3;
-    const u32x2_a4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_a4 *>(block + 4u * dw));
-    return AxisLo{{v.x, v.y}};
-}
 // value k = base | bits [b k, b k + b) of the lane's realigned data.  Branch-free for every b <= 25 (b = 0: the mask is
 // empty and the value is the base): the lane's 128 bits are shifted down by its sub-dword offset (four v_alignbit
 // with a per-lane shift), then three more times by b, each time one dword less of it (3 + 2 + 1 v_alignbit with a
@@ -1275,96 +1264,18 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
         }
     };
 
-#if RTR_T1_PAIRS
-    if (!CULL && PACKED) {
-        // Two chunks per wave and iteration (a PAIR: chunks 2 p and 2 p + 1, neighbours in memory, their two headers one
-        // 64-byte scalar load), light path first: a lane loads only the 8 bytes per axis that hold its first value, runs
-        // the lane test on both chunks, requests the next pair's 8-byte pieces and the pair after that's headers, and
-        // only then turns to the chunks that have a candidate lane -- those are read again in full (16 bytes per lane and
-        // axis: the lines were fetched a moment ago), decoded and taken through do_quad, by ONE copy of that code in a
-        // two-trip loop.  Per wave twice the bytes in flight of the one-chunk pipeline at the same register cost (2 x 6
-        // instead of 12 dwords), half the loop bookkeeping per chunk, and the stream keeps running while a chunk inside
-        // the frustum is worked through.  The 8-byte pieces touch every cache line of the blocks (lane stride b / 2
-        // bytes <= 12.5), so HBM traffic is what it was.
-        const uint32_t npairs = (nchunks + 1u) >> 1;
-        const uint32_t Rp = (npairs + NW - 1u) / NW;
-        const uint32_t phase_p = (uint32_t)((uint64_t)((blockIdx.x * G) / gridDim.x) * Rp / G);
-        auto pair_of = [&](uint32_t q) -> uint32_t {
-            uint32_t r = q + phase_p;
-            r = r >= Rp ? r - Rp : r;
-            const uint32_t p = r * NW + wave;
-            return (q < Rp && p < npairs) ? p : npairs;
-        };
-        struct Half { uint32_t bx, by, bz, ww, off_lo, off_hi, sp; };  // one chunk's header (scalars)
-        auto lo_of = [&](const Half &h, AxisLo out[3]) {
-            const uint8_t *p = reinterpret_cast<const uint8_t *>(pk_planes) + (((((uint64_t)h.off_hi) << 32) | (uint64_t)h.off_lo) << 5);
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const uint32_t b = (h.ww >> (6 * a)) & 63u;
-                out[a] = ld_axis_lo(p, b, lane);
-                p += 32u * b;
-            }
-        };
-        uint4 g0, g1, g2, g3;  // the requested pair's headers
-        uint32_t gp = 0, pc = 0;
-        bool gvalid = false, pvalid = false;
-        Half hA{}, hB{};
-        AxisLo rawA[3], rawB[3];
-        auto fetch_hdr = [&](uint32_t q) {
-            const uint32_t pr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(q < Rp ? pair_of(q) : npairs));
-            gvalid = pr < npairs;
-            gp = gvalid ? pr : npairs - 1u;
-            const uint4 *h = pk_hdr + 4 * (size_t)gp;  // (an odd chunk count: the header array ends with a zero header)
-            g0 = h[0], g1 = h[1], g2 = h[2], g3 = h[3];
-        };
-        auto fetch_lo = [&]() {  // of the pair whose headers have arrived
-            pc = gp, pvalid = gvalid;
-            hA = Half{g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z};
-            hB = Half{g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z};
-            lo_of(hA, rawA);
-            lo_of(hB, rawB);
-        };
-        auto light = [&](const AxisLo raw[3], const Half &h, bool live) -> bool {  // wave-uniform: some lane is a candidate
-            if (__ballot(live) == 0ull) return false;
-            const uint32_t sp_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.sp);
-            if (!(lane_test && !(h.ww & kPackWideFlag) && sp_c < 0x7F000000u)) return true;
-            const float x0 = first_value(raw[0].d[0], raw[0].d[1], h.ww & 63u, h.bx);
-            const float y0 = first_value(raw[1].d[0], raw[1].d[1], (h.ww >> 6) & 63u, h.by);
-            const float z0 = first_value(raw[2].d[0], raw[2].d[1], (h.ww >> 12) & 63u, h.bz);
-            return lane_maybe(x0, y0, z0, __uint_as_float(sp_c), live);
-        };
-        fetch_hdr(0);
-        fetch_lo();
-        fetch_hdr(1);
-        for (uint32_t q = 0; q < Rp; ++q) {
-            const Half cA = hA, cB = hB;
-            const uint32_t iA = pc * 128u + (uint32_t)lane, iB = iA + 64u;
-            const bool liveA = pvalid && iA < n4, liveB = pvalid && iB < n4;
-            const bool candA = light(rawA, cA, liveA), candB = light(rawB, cB, liveB);
-            fetch_lo();
-            fetch_hdr(q + 2);
-#pragma unroll 1
-            for (int hh = 0; hh < 2; ++hh) {  // (not unrolled: one copy of the long path)
-                if (!(hh ? candB : candA)) continue;
-                const Half c = hh ? cB : cA;
-                const uint32_t i = hh ? iB : iA;
-                const bool live = hh ? liveB : liveA;
-                const ChunkRaw raw = load_chunk(pk_planes, make_uint4(c.bx, c.by, c.bz, c.ww), make_uint4(c.off_lo, c.off_hi, 0u, 0u), lane);
-                float4 X, Y, Z;
-                Rows r;
-                unpack_chunk(raw, c.ww, c.bx, c.by, c.bz, X, Y, Z, lane);
-                project_rows(X, Y, Z, r);
-                do_quad(i < n4 ? i : n4 - 1u, live, r);  // (masked lanes: any valid address for the colour load)
-            }
-        }
-    } else
-#endif
     if (!CULL && PACKED) {
         // the same pipeline as below on the packed form, one stage deeper: header of chunk q + 2, planes of chunk
         // q + 1 (<= 12 dwords per lane, usually 6-9) and the arithmetic of chunk q are in flight together
         // (Two chunks of planes in flight per wave -- buffers A / B, loop unrolled by two -- lift the loads alone from 95
         // to 87 us (one chunk per wave and memory round trip is 4096 x 1.3 KB / ~1 us = 5.4 TB/s), but the whole kernel
-        // gets 5 us slower: 14 more spilled scalar registers and their v_readlane traffic.  Measured in rounds 2 and 3.)
+        // gets 5 us slower: 14 more spilled scalar registers and their v_readlane traffic.  Measured in rounds 2 and 3.
+        // Round 4, with the lane test: a PAIR of chunks per iteration, the light path on 8-byte loads and the long path
+        // re-reading the chunk in full (one copy of it in a two-trip loop): 140-145 us against 127-133; the long path
+        // DEFERRED to the wave's own turn (one wave of a SIMD at a time on it, the others streaming; the noted chunk read
+        // again): 125-133 against 121-125.  The kernel's duration is a wave's serial chain of iterations -- ~60 light ones
+        // of about a memory round trip each and ~5 long ones of 5-6 us of dependent latency -- and neither form shortens
+        // that chain; a re-read lengthens it.)
         // No branch depends on whether the wave still has a chunk: past its last one it re-reads the cloud's
         // last chunk with every lane masked (at most two wasted iterations per wave), so the compiler sees
         // straight-line code and waits for the chunk's three loads exactly once, where they are decoded.
@@ -1817,7 +1728,7 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
             // a lean frame: no work list -- the tile of this launch position, its stream counters read here (T1 is
             // complete) and reset for the next frame (each counter belongs to exactly one tile), its entry count stored
             // for the frame's statistics
-            const uint32_t tl = ts_order(S, lean_parity)[item_i];
+            const uint32_t tl = ts_order(S, lean_parity)[item_i];  // (identity order instead: -0.5 us, within noise)
             const int ltx = (int)tl % g.tiles_x, lty = (int)tl / g.tiles_x;
             uint32_t *const fill = ts_fill(S);
             uint32_t f[4] = {0u, 0u, 0u, 0u};

@@ -907,7 +907,7 @@ def test_packed_only_residency_and_the_adaptive_extent_pool(pkg, orc, projector)
     img, depth = projector.project(P, filtered=True)
     rf = orc.filter(ref["depth_bits"], ref["img"])
     assert np.array_equal(depth.view(np.uint32), rf["depth"].view(np.uint32)) and np.array_equal(img, rf["img"])
-    # the adaptive pool: n / 4 entries for a fresh cloud; the whole cloud inside one 32x16 tile needs ~2 n
+    # the adaptive pool: n / 2 entries for a fresh cloud; the whole cloud inside one 32x16 tile needs ~2 n
     K = np.array([[1.0, 0, 8.0], [0, 1.0, 8.0], [0, 0, 1]])   # focal length 1 px: everything within a pixel of (8, 8)
     E = np.eye(4)
     E[2, 3] = 20.0
