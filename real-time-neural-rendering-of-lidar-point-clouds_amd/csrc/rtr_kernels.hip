@@ -361,6 +361,9 @@ constexpr int kTileThreadsCompact = RTR_TILE0_THREADS;  // k_tile<0> (see tile_b
 #define RTR_TILE0_WAVES 8
 #define RTR_TILE0_SWEEP 4
 #endif
+#ifndef RTR_TILE0_HEAD
+#define RTR_TILE0_HEAD 1  // k_tile<0>: tiles beyond one batch keep their first batch in registers too (tile_body)
+#endif
 #ifndef RTR_TILE0_AHEAD
 #define RTR_TILE0_AHEAD 1
 #endif
@@ -1777,6 +1780,10 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
         static_assert(T * TP2 <= kS0, "one batch must fit the static extent");
         const bool one_batch = (MODE == 0 || (MODE == 4 && occ4 == (1u << dsl.rank))) && !split && rec0.y <= lim && rec0.z <= lim &&
                                (ns == 2 || (rec0.w <= lim && rec1.x <= lim));
+        // MODE 0, tiles BEYOND one batch (most tiles of a 1e8-point frame): the first batch of every stream is requested
+        // and kept in registers all the same -- only what lies behind it is swept, i.e. read twice (round 3 swept
+        // everything: 108 MB moved for 54 MB of entries)
+        const bool head = RTR_TILE0_HEAD && MODE == 0 && !split && !one_batch;
         unsigned long long r[TB];
         auto load_batch = [&](auto per_tag) {  // (compile-time register -> stream mapping: everything stays in registers)
             constexpr int PER = decltype(per_tag)::value;
@@ -1795,7 +1802,7 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
                 }
             }
         };
-        if (one_batch) {
+        if (one_batch || head) {
             if (two) load_batch(std::integral_constant<int, TP2>{});
             else load_batch(std::integral_constant<int, TP4>{});
         }
@@ -1850,7 +1857,9 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
             if (st >= 0 && cnt > e_lo) {
                 const unsigned long long a = cnt * sub / nsub, b = cnt * (sub + 1u) / nsub;
                 const unsigned long long e_hi = (unsigned long long)kS0 << k;
-                const unsigned long long lo = a > e_lo ? a : e_lo, hi = b < e_hi ? b : e_hi;
+                unsigned long long lo = a > e_lo ? a : e_lo;
+                const unsigned long long hi = b < e_hi ? b : e_hi;
+                if (head && k == 0 && lo < lim) lo = lim;  // (the stream's first batch is in registers)
                 // (an extent that was never handed out in this frame, or that lies beyond the pool -- the adaptive pool
                 // overflowed, T1 has dropped its entries and flagged the frame -- is not read: the frame is repeated)
                 const unsigned long long de = k == 0 ? 0ull : ts_dir(S)[(size_t)st * kDirK + k];
@@ -1904,7 +1913,7 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
         const uint32_t nseg = s_nseg;
         uint32_t n_local = 0;
         for (uint32_t q = 0; q < nseg; ++q) n_local += s_seg_n[q];
-        if (one_batch) n_local = rec0.y + rec0.z + rec0.w + rec1.x;
+        if (one_batch || head) n_local = rec0.y + rec0.z + rec0.w + rec1.x;
         const bool do_min = MODE == 1 || MODE == 0 || MODE == 4 || MODE == 5;
         const bool do_acc = MODE == 2 || MODE == 3 || ((MODE == 0 || MODE == 4) && !split);
         // Accumulators: the exact layout is two 64-bit words per pixel, (c0 | c1 << 32) and
@@ -2131,16 +2140,20 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
             if (two) min_runs(std::integral_constant<int, TP2>{});
             else min_runs(std::integral_constant<int, TP4>{});
         } else if (do_min) {
+            if (head) {
+                if (two) min_runs(std::integral_constant<int, TP2>{});
+                else min_runs(std::integral_constant<int, TP4>{});
+            }
             sweep([&](const unsigned long long *v, uint32_t pb) __attribute__((always_inline)) { min_seq(v, pb); }, kPadMin);
         }
         RTR_TSTAMP(2);
         __syncthreads();
         RTR_TSTAMP(3);
         auto accumulate = [&](bool packed) __attribute__((always_inline)) {
-            if (one_batch) {
+            if (one_batch || head) {
                 if (two) acc_runs(std::integral_constant<int, TP2>{}, packed);
                 else acc_runs(std::integral_constant<int, TP4>{}, packed);
-                return;
+                if (one_batch) return;
             }
             sweep([&](const unsigned long long *v, uint32_t pb) __attribute__((always_inline)) { acc_seq(v, pb, packed); }, kPadAcc);
         };
