@@ -408,7 +408,8 @@ int alloc_cloud(rtr_ctx *c, uint64_t n) {
         HIP_TRY(c, hipMalloc((void **)&c->y, c->cap * 4));
         HIP_TRY(c, hipMalloc((void **)&c->z, c->cap * 4));
     }
-    if (n != c->n) {  // (the adaptive extent pool starts over)
+    if (n != c->n) {  // (the adaptive extent pool starts over; the peers of a sharded frame must map the new one)
+        if (c->p2p.open || c->p2p.red) p2p_release(c);
         c->pool_worst = false;
         c->entries_max = 0;
         if (c->entries_host) *c->entries_host = 0u;

@@ -1278,7 +1278,9 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
         // DEFERRED to the wave's own turn (one wave of a SIMD at a time on it, the others streaming; the noted chunk read
         // again): 125-133 against 121-125.  The kernel's duration is a wave's serial chain of iterations -- ~60 light ones
         // of about a memory round trip each and ~5 long ones of 5-6 us of dependent latency -- and neither form shortens
-        // that chain; a re-read lengthens it.)
+        // that chain; a re-read lengthens it.  An L2 PREFETCH of the chunk after next (its header held one step longer, one
+        // dword per 64 bytes of its blocks requested into a register nobody reads): 161-162 us against 122 -- a second
+        // pass of every line through L1 and the texture addresser costs far more than the shorter round trip gains.)
         // No branch depends on whether the wave still has a chunk: past its last one it re-reads the cloud's
         // last chunk with every lane masked (at most two wasted iterations per wave), so the compiler sees
         // straight-line code and waits for the chunk's three loads exactly once, where they are decoded.
@@ -1346,6 +1348,7 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
 #ifdef RTR_EXPERIMENT
         if (xp_sink == 0x12345678u && live) fill[0] = 0u;  // practically never; keeps the work alive
 #endif
+
     } else if (!CULL) {
         // Software pipeline: the coordinates of the wave's NEXT quad are requested as soon as the current
         // ones have gone through the matrix rows, i.e. before the long part of an in-frustum quad (claims,

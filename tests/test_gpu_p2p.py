@@ -9,6 +9,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 from conftest import ROOT
@@ -141,3 +142,46 @@ def test_cpp_multi_process_example(pkg, tmp_path):
     res = subprocess.run([exe, "3", "900000", "640", "480", "6"], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert res.stdout.startswith("ok: 3 ranks x 6 frames")
+
+
+def test_exchange_lifecycle_on_one_rank(pkg, orc):
+    """what silently closed the exchange under the peers.  With world = 1 (a rank maps only its own
+    buffers, no second process needed): option "overlap" and the exchange exclude each other in both orders; a frame on
+    the second tile-store set never releases the exported pool; a new cloud closes the exchange on the C side, the
+    library says so ("p2p_open") and the Python adapter forgets its mapping, so the next sharded frame runs the setup
+    again on every rank instead of raising on one."""
+    W, H, n = 320, 240, 200_000
+    xyzw, rgba = orc.generate("room_shell", 11, 0, n, n)
+    P = pkg.orbit_projection(3, W, H)
+    ref = orc.project(xyzw, rgba, P, W, H)
+    p = pkg.Projector(0)
+    try:
+        p.upload_points(xyzw, rgba)
+        p.set_resolution(W, H)
+        p.set_option("overlap", 1)
+        with pytest.raises(pkg.RtrError):
+            p.p2p_export()                      # the peers map ONE tile store
+        p.set_option("overlap", 0)
+        p.p2p_open(0, 1, [p.p2p_export()])
+        assert p.get_option("p2p_open") == 1 and p.get_option("pool_worst_case") == 0
+        with pytest.raises(pkg.RtrError):
+            p.set_option("overlap", 1)
+        p.p2p_render(P, False)
+        p.synchronize()
+        assert np.array_equal(p.download(pkg._lib.BUF_DEPTH).reshape(-1), ref["depth_bits"].reshape(-1))
+        assert p.get_option("p2p_open") == 1    # a frame closes nothing
+        lo = pkg.sharded.HipLocal(p)
+        lo._p2p_res = (W, H)
+        assert lo.p2p_res == (W, H)
+        p.upload_points(xyzw[: n // 2], rgba[: n // 2])   # a new cloud: the exported pool is replaced
+        assert p.get_option("p2p_open") == 0
+        assert lo.p2p_res is None                # ... and the adapter notices: setup again, collectively
+        p.p2p_open(0, 1, [p.p2p_export()])
+        p.p2p_render_owned(P, False, 0)
+        p.synchronize()
+        ref2 = orc.project(xyzw[: n // 2], rgba[: n // 2], P, W, H)
+        assert np.array_equal(p.download(pkg._lib.BUF_DEPTH).reshape(-1), ref2["depth_bits"].reshape(-1))
+        assert np.array_equal(p.download(pkg._lib.BUF_IMAGE).reshape(-1), ref2["img"].reshape(-1))
+        assert p.p2p_timeouts() == 0
+    finally:
+        p.close()
