@@ -42,6 +42,12 @@ for it in range(cases):
         P = pkg.orbit_projection(int(rng.integers(0, 1000)), W, H)
     pack = int(rng.choice([0, 1, 2, 2]))            # 2: packed whatever the cloud, decode verified on the device
     split = int(rng.choice([32768, 32768, 64, 1000]))
+    # round 4: lean frames only start eight frames after an upload -- render up to 14 frames (other poses) first;
+    # the lane test, the packed-only residency and the adaptive pool on / off
+    lean, lane_test, keep_soa, pool_worst = (int(rng.integers(0, 2)) for _ in range(4))
+    pre = int(rng.choice([0, 0, 3, 9, 10, 14]))
+    p.set_option("lean", lean); p.set_option("lane_test", lane_test)
+    p.set_option("keep_soa", keep_soa); p.set_option("pool_worst_case", pool_worst)
     p.set_option("mode", mode); p.set_option("cull", cull)
     p.set_option("overlap", overlap)
     p.set_option("pack", pack)
@@ -53,6 +59,8 @@ for it in range(cases):
         p.reorder_points()
     p.set_resolution(W, H)
     ref = orc.project(xyzw, rgba, P, W, H, params=prm)
+    for k in range(pre):
+        p.render(pkg.orbit_projection(int(rng.integers(0, 1000)), W, H), bool(k & 1))
     img, depth = p.project(P)
     ok = np.array_equal(depth.view(np.uint32), ref["depth_bits"]) and np.array_equal(img, ref["img"])
     if ok and filt:
@@ -67,9 +75,9 @@ for it in range(cases):
     if not ok:
         print("MISMATCH", dict(it=it, W=W, H=H, n=n, scene=scene, mode=mode, cull=cull, reorder=reorder, filt=filt,
                                levels=levels, overlap=overlap, pack=pack, split=split, window=prm.depth_window, strength=prm.filter_strength,
-                               thr=prm.gradient_threshold))
+                               thr=prm.gradient_threshold, lean=lean, lane_test=lane_test, keep_soa=keep_soa, pool_worst=pool_worst, pre=pre))
         if os.environ.get("FUZZ_DIAG"):  # which option makes the difference (same cloud, same pose)
-            for key, val in (("overlap", 0), ("pack", 0), ("split_threshold", 32768), ("cull", 0), ("mode", 0)):
+            for key, val in (("lean", 0), ("lane_test", 0), ("overlap", 0), ("pack", 0), ("split_threshold", 32768), ("cull", 0), ("mode", 0)):
                 p.set_option(key, val)
                 if key == "split_threshold":
                     p.set_option("split_slice", 16384)
