@@ -1280,7 +1280,12 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
         // of about a memory round trip each and ~5 long ones of 5-6 us of dependent latency -- and neither form shortens
         // that chain; a re-read lengthens it.  An L2 PREFETCH of the chunk after next (its header held one step longer, one
         // dword per 64 bytes of its blocks requested into a register nobody reads): 161-162 us against 122 -- a second
-        // pass of every line through L1 and the texture addresser costs far more than the shorter round trip gains.)
+        // pass of every line through L1 and the texture addresser costs far more than the shorter round trip gains.  The
+        // planes staged through an LDS RING by LDS-DMA (global_load_lds_dwordx4, two slots per wave, the planes of chunk
+        // q + 2 requested as soon as chunk q has been read out of its slot: two chunks in flight per wave, no register holds
+        // data in flight; bit-exact at the first attempt): 121.4-121.6 us against 120.2-120.8, 1e7 points 22.1-22.6 against
+        // 22.7-22.9 -- twice the bytes in flight buy nothing: the stream part of the launch already runs at the rate
+        // the chip sustains, what is left is the chain of the chunks inside the frustum.)
         // No branch depends on whether the wave still has a chunk: past its last one it re-reads the cloud's
         // last chunk with every lane masked (at most two wasted iterations per wave), so the compiler sees
         // straight-line code and waits for the chunk's three loads exactly once, where they are decoded.
