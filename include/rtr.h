@@ -104,6 +104,13 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          and reset their stream counters themselves, one extra workgroup does the frame's bookkeeping off the
  *          critical path (5-6 us per frame).  0 = always the epilogue.  After a lean frame rtr_accumulate_pass
  *          re-projects the cloud (the bins were consumed).
+ *  "lean_identity": 1 (default) = in a lean frame tile workgroup b takes tile b -- no look-up in the launch order
+ *          (heaviest tiles first) -- whenever every workgroup of the tile launch is resident at once (1080p: 2041
+ *          of 2048 slots), where the order buys nothing and costs a dependent memory round trip.  0 = always the order.
+ *  "lean_early": lean frames: the tile workgroups request their first batch of entries BEFORE they know the
+ *          streams' lengths (one round trip less; right when most tiles are full) -- 1 always, 0 never (after the
+ *          lengths, from indices clamped to them: a near-empty tile then moves no stale memory), -1 (default) = when
+ *          the previous frame had at least 1024 entries per tile on average.  Same frame either way.
  *  "lane_test": 1 (default) = the tile-binned point kernel first decodes and projects ONE point per lane (of
  *          the four consecutive points a lane holds) and bounds the other three by the chunk's "lane spread"
  *          (the largest coordinate difference inside a lane, measured once per upload): a 256-point chunk with

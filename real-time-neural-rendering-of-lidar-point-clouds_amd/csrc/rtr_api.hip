@@ -43,6 +43,9 @@ struct rtr_ctx {
     int last_filter = 0;        // the adaptive extent pool was too small for it
     bool last_valid = false;
     int opt_lean = 1;           // whole single-GPU frames without split tiles end T1 without its epilogue (option "lean")
+    int opt_lean_identity = 1;  // lean frames: tile workgroup b takes tile b when the whole launch is resident (option "lean_identity")
+    int opt_lean_early = -1;    // lean frames: first batch of entries requested before the stream counters are known: 0 never,
+                                // 1 always, -1 when the previous frame's tiles were full (option "lean_early")
     bool last_lean = false;     // the last binned frame was a lean one (its statistics are folded on demand) ...
     int lean_parity = 0;        // ... and this was its parity
     uint64_t n = 0, cap = 0;
@@ -800,6 +803,15 @@ int rtr_set_option(rtr_ctx *c, const char *key, int value) {
         c->opt_lean = value != 0;
         return RTR_OK;
     }
+    if (!strcmp(key, "lean_identity")) {  // lean frames: workgroup b = tile b when every tile workgroup is resident at once
+        c->opt_lean_identity = value != 0;
+        return RTR_OK;
+    }
+    if (!strcmp(key, "lean_early")) {  // lean frames: entries requested before the counters (tile_body); -1 = by the last frame
+        NEED(c, value >= -1 && value <= 1, "lean_early: -1, 0 or 1");
+        c->opt_lean_early = value;
+        return RTR_OK;
+    }
     if (!strcmp(key, "lane_test")) {  // T1: one point per lane first (k_project_bin); 0 = every point, as in round 3
         c->opt_lane_test = value != 0;
         c->list_valid = false;
@@ -855,6 +867,8 @@ int rtr_get_option(rtr_ctx *c, const char *key, int *value) {
     else if (!strcmp(key, "cull")) *value = c->opt_cull;
     else if (!strcmp(key, "lane_test")) *value = c->opt_lane_test;
     else if (!strcmp(key, "lean")) *value = c->opt_lean;
+    else if (!strcmp(key, "lean_identity")) *value = c->opt_lean_identity;
+    else if (!strcmp(key, "lean_early")) *value = c->opt_lean_early;
     else if (!strcmp(key, "p2p_open")) *value = c->p2p.open ? 1 : 0;  // the peers' buffers are mapped (rtr_p2p_open)
     else if (!strcmp(key, "keep_soa")) *value = c->opt_keep_soa;
     else if (!strcmp(key, "pool_worst_case")) *value = c->opt_pool_worst;
@@ -1398,8 +1412,18 @@ int rtr_render(rtr_ctx *c, const float P[16], int with_filter) {
         }
         {
             Timed t(c, RTR_K_TILE);
+            // (lean frames, tile_body: bit 5 = no launch order when the launch is resident at once; bit 6 = the first batch
+            // of entries before the counters, when the tiles are expected full: the last frame's entry count -- a mapped
+            // word, no sync -- is at least half a batch, 1024 entries, per tile)
+            int lean_bits = 0;
+            if (lean) {
+                lean_bits = 8 | (c->opt_lean_identity ? 32 : 0);
+                const uint64_t e_last = c->entries_host ? __atomic_load_n(c->entries_host, __ATOMIC_RELAXED) : 0u;
+                if (c->opt_lean_early > 0 || (c->opt_lean_early < 0 && e_last >= 1024ull * (uint64_t)rtr::tile_count(c->W, c->H)))
+                    lean_bits |= 64;
+            }
             rtr::launch_tile(c->stream, 0, c->W, c->H, c->F().store, c->prm.depth_window, c->depth, c->acc, c->img,
-                             c->opt_keep_accum | (lean ? 8 : 0) | (c->lean_parity << 4), pyr.enable ? &pyr : nullptr);
+                             c->opt_keep_accum | lean_bits | (c->lean_parity << 4), pyr.enable ? &pyr : nullptr);
             if (lean) c->list_valid = false;  // (the tile launch has consumed and reset the stream counters)
             // tiles heavier than option "split_threshold" are split over several workgroups: a second launch takes
             // the minimum over each slice (they meet in the depth buffer), then -- behind a barrier over its 256
@@ -1850,6 +1874,8 @@ extern "C" int rtr_debug_stamps(rtr_ctx *c, unsigned long long out[64]) {  // ti
     if (!c || !out || !c->F().store.meta) return RTR_ERR_INVALID;
     DevGuard g(c->device);
     HIP_TRY(c, hipMemcpyAsync(out, rtr::ts_dbg(c->F().store), 64 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemsetAsync(rtr::ts_dbg(c->F().store) + 40, 0, 8 * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(rtr::ts_dbg(c->F().store) + 56, 0, 8 * 8, c->stream));  // (the per-wave maxima / sums of T1)
     HIP_TRY(c, sync_streams(c));
     return RTR_OK;
 }

@@ -1030,6 +1030,20 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
     // 16 chunks to each wave instead cost +50 us), and every wave still samples the whole cloud.
     const uint32_t nchunks = (n4 + 63u) / 64u, NW = gridDim.x * (kBlock / 64), wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t R = (nchunks + NW - 1u) / NW;
+#ifdef RTR_EXPERIMENT  // (how long do the waves run, how are the long chunks dealt: tools/stamps.py)
+    const unsigned long long t_wave0 = wall_clock64();
+    if (lane == 0 && (wave & 63u) == 0u) atomicMax(ts_dbg(S) + 59, ~t_wave0);
+#endif
+    // (LOAD BALANCE, measured in round 4 and not kept.  The launch ends with its most loaded wave: the chunks that take
+    // the long path -- ~4.5 us each against ~1 us for a chunk that only streams -- come in runs shorter than a round, so
+    // the waves hold 5 +- 1.5 of them, up to 9 on C3, and T1 = the stream + 9 x 4.5 us where the average wave has 5;
+    // an RTR_EXPERIMENT build's histogram of the waves' durations shows the same +-17 us.  (a) A queue in device memory
+    // for the candidates of waves past the previous frame's average + 1..3, served by the waves that have finished --
+    // tickets, one waiter per slot, compare-and-swap on leaving so that every chunk is processed exactly once, bit-exact:
+    // T1 137-197 us against 123 -- a hand-over costs its wave two dependent round trips, about what the chunk would
+    // have cost, and the helpers only exist once their own share is done.  (b) The same inside a workgroup, through LDS,
+    // its four waves dealt shares a quarter of a round apart so that their loads are independent: 120.5-122.5 against
+    // 123 on C3, 25.8-26.4 against 23.5 on the 1e7-point cloud, whose stream the four fronts slow down.)
     // cblock = 0 (the default): one group, unless the PREVIOUS frame of this tile store had more than a quarter
     // of the cloud inside the frustum (its entry count is still in the header; T1's epilogue rewrites it when
     // every workgroup is past this line).  Then the claims, not the stream, bound the kernel -- ~390 k wave
@@ -1449,6 +1463,25 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
             }
         }
     }
+#ifdef RTR_EXPERIMENT
+    if (lane == 0) {
+        const unsigned long long t_end = wall_clock64();
+        // (same-address atomics serialise, ~90 per us, and hold up the claims behind them: a SAMPLE of the waves reports)
+        if ((blockIdx.x & 7u) == 0u) {  // histogram of the waves' own durations, 10 us bins from 40 us
+            const unsigned long long us = (t_end - t_wave0) / 100ull;
+            const int bin = us < 60ull ? 0 : (us >= 200ull ? 7 : (int)((us - 60ull) / 20ull));
+            atomicAdd(ts_dbg(S) + 40 + bin, 1ull);
+        }
+        if ((wave & 63u) == 0u) {
+            atomicMax(ts_dbg(S) + 57, t_end);
+            atomicMax(ts_dbg(S) + 61, (unsigned long long)n_colour);
+            atomicMax(ts_dbg(S) + 56, ~t_end);
+            atomicAdd(ts_dbg(S) + 58, t_end);
+            atomicAdd(ts_dbg(S) + 60, 1ull);
+            atomicAdd(ts_dbg(S) + 62, (unsigned long long)n_colour);
+        }
+    }
+#endif
     if (clear_split & 8) {
         // a LEAN frame (lean_frame_end): no ticket, no epilogue -- the tile kernel's workgroups read the stream counters
         // themselves.  Only the colour-chunk statistic leaves, one fire-and-forget add per wave that has any.
@@ -1688,6 +1721,14 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
     const bool sparse = (write_acc & 4) != 0;
     const bool lean = MODE == 0 && (write_acc & 8) != 0;  // (see lean_frame_end)
     const int lean_parity = (write_acc >> 4) & 1;          // (every mode-0 / mode-1 launch: which order[] NOT to write)
+    // a lean frame's tile workgroup starts with a chain of dependent round trips: launch order -> stream counters ->
+    // entries.  Bit 5: every tile workgroup of the launch is resident at once (launch_tile), so the launch order buys
+    // nothing and workgroup b takes tile b.  Bit 6 (the host expects full tiles: the previous frame had them): the
+    // first batch of entries is requested BEFORE the counters are known -- the addresses depend on the tile alone --
+    // and masked when they arrive; with sparse tiles (bit 6 clear) the batch is requested after the counters, from
+    // indices clamped to the stream's length, so that a near-empty tile does not pull 16 KB of stale entries.
+    const bool lean_ident = lean && (write_acc & 32) != 0;
+    const bool lean_early = lean && RTR_TILE0_HEAD && (write_acc & 64) != 0;
     write_acc &= 1;
     const uint4 *const records = reinterpret_cast<const uint4 *>(ts_items(S));
     // Records [0, ntiles): one tile each, for workgroups 0 .. ntiles - 1; records [ntiles, ...): the slices of
@@ -1719,13 +1760,29 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
 
     for (uint32_t item_i = kQueue ? take() : first; tile_wg || item_i < nt + n_split; item_i = kQueue ? take() : item_i + split_step) {
 #ifdef RTR_EXPERIMENT
-        const bool stamp = MODE == 0 && (blockIdx.x == 5 || blockIdx.x == 700 || blockIdx.x == 1900);
+        const bool stamp = MODE == 0 && (blockIdx.x == 5 || blockIdx.x == 700);  // (words 40..: T1's wave histogram)
         const int sb = blockIdx.x == 5 ? 8 : (blockIdx.x == 700 ? 24 : 40);
 #define RTR_TSTAMP(k) do { if (stamp && tid == 0) ts_dbg(S)[sb + (k)] = wall_clock64(); } while (0)
 #else
 #define RTR_TSTAMP(k) do { } while (0)
 #endif
         RTR_TSTAMP(0);
+        typedef const unsigned long long __attribute__((address_space(1))) *entries_t;
+        constexpr unsigned long long kPadMin = (unsigned long long)RTR_EMPTY << 33;  // never lowers a minimum
+        constexpr unsigned long long kPadAcc = 0x7F800000ull << 33;                  // +inf fails every window test
+        unsigned long long r[TB];  // the first batch of the tile's entries (see below)
+        // request a tile's first batch without knowing the streams' lengths (the addresses depend on the tile alone; e <
+        // T * PER lies inside the static extent whatever the length): mask_batch() settles what counts
+        auto request_batch = [&](auto per_tag, int tx_, int ty_) {
+            constexpr int PER = decltype(per_tag)::value;
+#pragma unroll
+            for (int q = 0; q < TB / PER; ++q) {
+                const int st = stream_tile(g, tx_, ty_, q);
+                const entries_t src = (entries_t)(S.ext0 + ((size_t)(st >= 0 ? st : 0) << kS0Shift));
+#pragma unroll
+                for (int j = 0; j < PER; ++j) r[q * PER + j] = src[tid * PER + j];
+            }
+        };
         // one 32-byte record per work item: everything the workgroup needs to find its entries
         uint4 rec0, rec1;
         uint32_t occ4 = 0u;  // mode 4: the ranks that have points in this tile
@@ -1739,8 +1796,12 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
             // a lean frame: no work list -- the tile of this launch position, its stream counters read here (T1 is
             // complete) and reset for the next frame (each counter belongs to exactly one tile), its entry count stored
             // for the frame's statistics
-            const uint32_t tl = ts_order(S, lean_parity)[item_i];  // (identity order instead: -0.5 us, within noise)
+            const uint32_t tl = lean_ident ? item_i : ts_order(S, lean_parity)[item_i];
             const int ltx = (int)tl % g.tiles_x, lty = (int)tl / g.tiles_x;
+            if (lean_early) {  // (workgroup-uniform)
+                if (g.tw_shift == 5) request_batch(std::integral_constant<int, TB / 2>{}, ltx, lty);
+                else request_batch(std::integral_constant<int, TB / 4>{}, ltx, lty);
+            }
             uint32_t *const fill = ts_fill(S);
             uint32_t f[4] = {0u, 0u, 0u, 0u};
             const int nsl = 2 << (g.tw_shift - 5);
@@ -1775,9 +1836,6 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
         const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
         const int tx0 = tx << g.tw_shift, ty0 = ty * kTileH;
         // (the segment pointers come out of LDS as integers: say that they are global memory, or the loads go flat)
-        typedef const unsigned long long __attribute__((address_space(1))) *entries_t;
-        constexpr unsigned long long kPadMin = (unsigned long long)RTR_EMPTY << 33;  // never lowers a minimum
-        constexpr unsigned long long kPadAcc = 0x7F800000ull << 33;                  // +inf fails every window test
         // Most tiles hold fewer entries than one batch of the workgroup (8 per thread) in the static extents
         // of their two (four) streams: those are requested right here, before the LDS tile is even
         // initialised, read ONCE and kept in registers across the barrier between the two reference passes.
@@ -1792,27 +1850,34 @@ __device__ __forceinline__ void tile_body(const TileStore &S, const TileGeom &g,
         // and kept in registers all the same -- only what lies behind it is swept, i.e. read twice (round 3 swept
         // everything: 108 MB moved for 54 MB of entries)
         const bool head = RTR_TILE0_HEAD && MODE == 0 && !split && !one_batch;
-        unsigned long long r[TB];
-        auto load_batch = [&](auto per_tag) {  // (compile-time register -> stream mapping: everything stays in registers)
+        auto load_batch = [&](auto per_tag, auto loaded_tag) {  // (compile-time register -> stream mapping: everything stays in registers)
             constexpr int PER = decltype(per_tag)::value;
+            constexpr bool kLoaded = decltype(loaded_tag)::value;  // request_batch() has been here: only mask
 #pragma unroll
             for (int q = 0; q < TB / PER; ++q) {
                 const int st = stream_tile(g, tx, ty, q);
                 const entries_t src = (entries_t)(S.ext0 + ((size_t)(st >= 0 ? st : 0) << kS0Shift));
                 const uint32_t cq = q == 0 ? rec0.y : (q == 1 ? rec0.z : (q == 2 ? rec0.w : rec1.x));
+                // unconditional loads (a load that merges with a constant at the end of a branch is waited for on the
+                // spot), masked after; a thread whose entries lie past the stream's end re-reads the stream's first ones
+                // (lines its neighbours hold anyway) instead of pulling stale memory: a sparse frame's tile kernel moved
+                // 16 KB per tile whatever the tile held
+                const uint32_t b = tid * PER, bc = b < cq ? b : 0u;
 #pragma unroll
                 for (int j = 0; j < PER; ++j) {
-                    // unconditional load (e < 2048 lies inside the static extent whatever the stream's length; a
-                    // load that merges with a constant at the end of a branch is waited for on the spot), masked after
-                    const uint32_t e = tid * PER + j;
-                    const unsigned long long got = src[e];
-                    r[q * PER + j] = (st >= 0 && e < cq) ? got : kPadAcc;  // (+inf lowers no minimum)
+                    const unsigned long long got = kLoaded ? r[q * PER + j] : src[bc + j];
+                    r[q * PER + j] = (st >= 0 && b + j < cq) ? got : kPadAcc;  // (+inf lowers no minimum)
                 }
             }
         };
         if (one_batch || head) {
-            if (two) load_batch(std::integral_constant<int, TP2>{});
-            else load_batch(std::integral_constant<int, TP4>{});
+            if (lean_early) {
+                if (two) load_batch(std::integral_constant<int, TP2>{}, std::true_type{});
+                else load_batch(std::integral_constant<int, TP4>{}, std::true_type{});
+            } else {
+                if (two) load_batch(std::integral_constant<int, TP2>{}, std::false_type{});
+                else load_batch(std::integral_constant<int, TP4>{}, std::false_type{});
+            }
         }
         auto stream_pb = [&](int q) -> uint32_t {  // where stream q's 32x16 storage tile sits in the processing tile
             const int per_row = 1 << (g.tw_shift - 5);
@@ -2682,9 +2747,31 @@ void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, floa
     TilePyr none{};
     none.enable = 0;
     const dim3 grid(g.ntiles + kHeavyExtra), grid1(g.ntiles + kHeavyExtra + 1), block(kTileThreads);
-    if (mode == 0)  // (the tiles + one workgroup for the next frame's launch order; split tiles' slices: k_tile_split)
-        hipLaunchKernelGGL(k_tile<0>, dim3(g.ntiles + 1), dim3(kTileThreadsCompact), 3 * tpix * sizeof(uint32_t) + 3 * tpix, s, S, g, W, H,
-                           window, depth, acc, img, write_acc & (1 | 8 | 16), pyr ? *pyr : none, nosl);  // (8, 16: lean frame, parity)
+    if (mode == 0) {  // (the tiles + one workgroup for the next frame's launch order; split tiles' slices: k_tile_split)
+        const size_t lds0 = 3 * tpix * sizeof(uint32_t) + 3 * tpix;
+        // bit 5 (workgroup b takes tile b) is granted when the whole launch is resident at once: asked of the runtime once
+        // per device and tile size
+        int flags = write_acc & (1 | 8 | 16 | 64);  // (8, 16: lean frame, parity; 64: first batch before the counters)
+        if (write_acc & 32) {
+            static int resident[kGridCacheDevices][2] = {{0}};
+            int dev_now = 0;
+            if (hipGetDevice(&dev_now) == hipSuccess && dev_now >= 0 && dev_now < kGridCacheDevices) {
+                int cap = __atomic_load_n(&resident[dev_now][g.tw_shift - 5], __ATOMIC_RELAXED);
+                if (cap == 0) {
+                    int per_cu = 0, cus = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tile<0>, kTileThreadsCompact, lds0) != hipSuccess ||
+                        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_now) != hipSuccess || per_cu < 1 || cus < 1)
+                        cap = -1;
+                    else
+                        cap = per_cu * cus;
+                    __atomic_store_n(&resident[dev_now][g.tw_shift - 5], cap, __ATOMIC_RELAXED);
+                }
+                if (cap >= g.ntiles + 1) flags |= 32;
+            }
+        }
+        hipLaunchKernelGGL(k_tile<0>, dim3(g.ntiles + 1), dim3(kTileThreadsCompact), lds0, s, S, g, W, H, window, depth, acc, img, flags,
+                           pyr ? *pyr : none, nosl);
+    }
     else if (mode == 3)  // the split tiles' slices, min phase then second phase: every workgroup leaves at once on ordinary frames
         hipLaunchKernelGGL(k_tile_split, dim3(kSplitGrid), block, 5 * tpix * sizeof(uint32_t) + 3 * tpix, s, S, g, W, H, window, depth,
                            acc, img, write_acc & 1, pyr ? *pyr : none, nosl);

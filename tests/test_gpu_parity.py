@@ -834,8 +834,12 @@ def test_lean_frames_match_the_epilogue_form(pkg, orc, projector):
     projector.set_resolution(W, H)
     poses = [pkg.orbit_projection(k, W, H) for k in (0, 140, 275, 410, 555, 690, 835, 970)]
     stats = {}
-    for lean in (1, 0, 1):
+    # (lean_identity / lean_early: how a lean frame's tile workgroup finds its tile and when it requests its entries)
+    forms = ((1, 1, -1), (0, 1, -1), (1, 1, -1), (1, 0, 0), (1, 1, 1), (1, 0, 1), (1, 1, 0))
+    for lean, ident, early in forms:
         projector.set_option("lean", lean)
+        projector.set_option("lean_identity", ident)
+        projector.set_option("lean_early", early)
         for k, P in enumerate(poses):
             filtered = bool(k & 1)
             img, depth = projector.project(P, filtered=filtered)
@@ -847,15 +851,16 @@ def test_lean_frames_match_the_epilogue_form(pkg, orc, projector):
             if filtered:
                 rf = orc.filter(rd, ri)
                 rd, ri = rf["depth"].view(np.uint32), rf["img"]
-            assert np.array_equal(depth.view(np.uint32), rd) and np.array_equal(img, ri), (lean, k)
+            assert np.array_equal(depth.view(np.uint32), rd) and np.array_equal(img, ri), (lean, ident, early, k)
             if k == 3:  # the phase calls between two lean frames (they bin for themselves)
                 projector.clear(); projector.min_depth_pass(P); projector.accumulate_pass(P); projector.resolve()
                 assert np.array_equal(projector.download(pkg._lib.BUF_DEPTH), ref["depth_bits"])
                 assert np.array_equal(projector.download(pkg._lib.BUF_IMAGE), ref["img"])
     for k, rows in stats.items():
-        assert rows[0] == rows[1] == rows[2] and rows[0][0] > 0, (k, rows)
+        assert all(row == rows[0] for row in rows) and len(rows) == len(forms) and rows[0][0] > 0, (k, rows)
     # frames WITHOUT a statistics call in between (the next lean frame folds the previous one's), then the last one's
     projector.set_option("lean", 1)
+    projector.set_option("lean_early", -1)
     for P in poses:
         projector.render(P, True)
     st = projector.frame_stats()
@@ -863,9 +868,13 @@ def test_lean_frames_match_the_epilogue_form(pkg, orc, projector):
     # 64-wide tiles (four streams per tile) and an empty cloud
     projector.set_resolution(3840, 2160)
     P4 = pkg.orbit_projection(3, 3840, 2160)
-    img, depth = projector.project(P4)
     ref = orc.project(xyzw, rgba, P4, 3840, 2160)
-    assert np.array_equal(depth.view(np.uint32), ref["depth_bits"]) and np.array_equal(img, ref["img"])
+    for early in (-1, 1, 0):  # (8160 tiles: more than are resident at once, so the launch order stays in use)
+        projector.set_option("lean_early", early)
+        for _ in range(2):
+            img, depth = projector.project(P4)
+            assert np.array_equal(depth.view(np.uint32), ref["depth_bits"]) and np.array_equal(img, ref["img"]), early
+    projector.set_option("lean_early", -1)
     projector.upload_points(np.zeros((0, 4), np.float32), np.zeros((0, 4), np.uint8))
     img, depth = projector.project(P4)
     assert (depth.view(np.uint32) == 0x7F7FFFFF).all() and not img.any()

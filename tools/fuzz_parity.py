@@ -47,6 +47,8 @@ for it in range(cases):
     lean, lane_test, keep_soa, pool_worst = (int(rng.integers(0, 2)) for _ in range(4))
     pre = int(rng.choice([0, 0, 3, 9, 10, 14]))
     p.set_option("lean", lean); p.set_option("lane_test", lane_test)
+    lean_ident, lean_early = int(rng.integers(0, 2)), int(rng.integers(-1, 2))
+    p.set_option("lean_identity", lean_ident); p.set_option("lean_early", lean_early)
     p.set_option("keep_soa", keep_soa); p.set_option("pool_worst_case", pool_worst)
     p.set_option("mode", mode); p.set_option("cull", cull)
     p.set_option("overlap", overlap)
@@ -75,7 +77,7 @@ for it in range(cases):
     if not ok:
         print("MISMATCH", dict(it=it, W=W, H=H, n=n, scene=scene, mode=mode, cull=cull, reorder=reorder, filt=filt,
                                levels=levels, overlap=overlap, pack=pack, split=split, window=prm.depth_window, strength=prm.filter_strength,
-                               thr=prm.gradient_threshold, lean=lean, lane_test=lane_test, keep_soa=keep_soa, pool_worst=pool_worst, pre=pre))
+                               thr=prm.gradient_threshold, lean=lean, lean_ident=lean_ident, lean_early=lean_early, lane_test=lane_test, keep_soa=keep_soa, pool_worst=pool_worst, pre=pre))
         if os.environ.get("FUZZ_DIAG"):  # which option makes the difference (same cloud, same pose)
             for key, val in (("lean", 0), ("lane_test", 0), ("overlap", 0), ("pack", 0), ("split_threshold", 32768), ("cull", 0), ("mode", 0)):
                 p.set_option(key, val)

@@ -19,12 +19,15 @@ def main():
     ap.add_argument("--scenes", default="room_shell,uniform_box")
     ap.add_argument("--options", default="mode=0;mode=1")
     ap.add_argument("--filter", type=int, default=1)
+    ap.add_argument("--pre", default="", help="options set BEFORE the cloud is generated, e.g. auto_reorder=0")
     args = ap.parse_args()
     pkg = entry.load_package()
     W, H, n = args.width, args.height, args.points
     p = pkg.Projector(0)
     p.set_resolution(W, H)
     poses = [pkg.orbit_projection(k, W, H) for k in range(args.frames + 3)]
+    for kv in filter(None, args.pre.split(",")):
+        p.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     for scene in args.scenes.split(","):
         p.generate_synthetic(scene, 0xC0FFEE03, 0, n, n)
         for optset in args.options.split(";"):
