@@ -50,7 +50,7 @@ struct rtr_ctx {
     int lean_parity = 0;        // ... and this was its parity
     uint64_t n = 0, cap = 0;
     uint4 *pk_hdr = nullptr;        // rtr::PackedXyz of the resident cloud (option "pack"); null: not in use
-    uint32_t *pk_planes = nullptr;
+    uint32_t *pk_planes = nullptr, *pk_planes_b = nullptr;  // (one allocation: A streams, then B streams)
     uint64_t pk_bytes = 0;          // headers + planes
     int opt_pack = 1;               // 0 never, 1 when it saves >= 1/8 of the coordinate stream, 2 always + verified after packing
 
@@ -278,6 +278,7 @@ void free_lists(rtr_ctx *c) {  // the dynamic extent pools (sized by the point c
 
 void free_pack(rtr_ctx *c) {
     dfree(c->pk_hdr); dfree(c->pk_planes);
+    c->pk_planes_b = nullptr;
     c->pk_bytes = 0;
 }
 
@@ -382,7 +383,7 @@ int ensure_soa(rtr_ctx *c) {
     HIP_TRY(c, hipMalloc((void **)&c->x, c->cap * 4));
     HIP_TRY(c, hipMalloc((void **)&c->y, c->cap * 4));
     HIP_TRY(c, hipMalloc((void **)&c->z, c->cap * 4));
-    rtr::unpack_to_soa(c->stream, rtr::PackedXyz{c->pk_hdr, c->pk_planes}, c->n, c->x, c->y, c->z);
+    rtr::unpack_to_soa(c->stream, rtr::PackedXyz{c->pk_hdr, c->pk_planes, c->pk_planes_b}, c->n, c->x, c->y, c->z);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, RTR_ERR_HIP, "unpack launch failed: %s", hipGetErrorString(e));
     return RTR_OK;
@@ -435,7 +436,7 @@ rtr::Cloud cloud_of(const rtr_ctx *c) {
     // cloud measures ~1.0; the reference loader's 0.25 m blocks in hash-map order, unordered inside, measure 0.28 for a
     // 10 m room and must keep the wave-level claim groups: 0.33 ms instead of 0.66 ms per frame without them)
     return rtr::Cloud{c->x, c->y, c->z, c->rgba, c->n, c->opt_grid, (!c->reordered && c->order_ratio > 0.5f) ? 1 : 0,
-                      rtr::PackedXyz{c->pk_hdr, c->pk_planes}, c->spread, {c->absmax[0], c->absmax[1], c->absmax[2]}};
+                      rtr::PackedXyz{c->pk_hdr, c->pk_planes, c->pk_planes_b}, c->spread, {c->absmax[0], c->absmax[1], c->absmax[2]}};
 }
 
 struct Timed {  // brackets one phase with hipEvents on the stream it is launched on
@@ -999,12 +1000,15 @@ static int pack_cloud(rtr_ctx *c) {
     if (hipStreamSynchronize(c->stream) != hipSuccess) return give_up();
     const uint64_t bytes = host[0] * 32 + nchunks * 32;  // blocks (32-byte units) + headers
     if (c->opt_pack == 1 && bytes * 8 > n4 * 48 * 7) return give_up();  // saves less than 1/8 of the 12 B/pt stream
-    // (spare bytes: the last lanes' 16-byte loads run up to 12 bytes past the chunk's last value)
-    if (hipMalloc((void **)&planes, (host[0] + 2) * 32) != hipSuccess) return give_up();
-    if (hipMemsetAsync(planes + host[0] * 8, 0, 64, c->stream) != hipSuccess) return give_up();
-    rtr::pack_write(c->stream, cl, hdr, planes);
+    // (one allocation: the A streams, 64 spare bytes, the B streams, 64 spare bytes -- the last lanes' loads run up to
+    // 12 bytes past the last value of their stream)
+    const uint64_t b_dw = rtr::pack_b_dwords(host[0]);
+    if (hipMalloc((void **)&planes, rtr::pack_total_dwords(host[0]) * 4) != hipSuccess) return give_up();
+    if (hipMemsetAsync(planes + host[0] * 2, 0, (b_dw - host[0] * 2) * 4, c->stream) != hipSuccess) return give_up();
+    if (hipMemsetAsync(planes + b_dw + host[0] * 6, 0, 64, c->stream) != hipSuccess) return give_up();
+    rtr::pack_write(c->stream, cl, hdr, planes, planes + b_dw);
     if (c->opt_pack == 2) {
-        rtr::pack_verify(c->stream, cl, hdr, planes, (uint64_t *)tot.p + 1);
+        rtr::pack_verify(c->stream, cl, hdr, planes, planes + b_dw, (uint64_t *)tot.p + 1);
         if (hipMemcpyAsync(host, tot.p, sizeof host, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return give_up();
     }
     if (hipStreamSynchronize(c->stream) != hipSuccess) return give_up();
@@ -1014,6 +1018,7 @@ static int pack_cloud(rtr_ctx *c) {
     }
     c->pk_hdr = hdr;
     c->pk_planes = planes;
+    c->pk_planes_b = planes + b_dw;
     c->pk_bytes = bytes;
     return RTR_OK;
 }

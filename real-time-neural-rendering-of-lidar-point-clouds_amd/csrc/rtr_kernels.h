@@ -18,20 +18,29 @@ struct Proj {
 // chunk and axis the fp32 BIT PATTERNS are stored as base | low bits: base = the leading bits all 256
 // patterns share (low b bits clear), b = 0..25 or 32 the number of bits below that common prefix (0: the axis
 // is constant in the chunk; 32: nothing is shared -- NaNs, mixed signs -- or more than 25 bits differ).  An
-// axis block is the 256 values' low b bits back to back as one little-endian bit stream (lane l's four values
-// at bit 4 b l): 32 b bytes, read with ONE dword-aligned 16-byte load per lane (the lane shifts its data down by
-// the 0..28 bits its first value starts into that dword); a chunk is its x, y, z blocks.
+// axis block is the 256 values' low b bits as TWO little-endian bit streams: the A stream holds the FIRST value of
+// every lane (lane l's b bits at bit b l: 8 b bytes), the B stream its other three (3 b bits at bit 3 b l: 24 b bytes) --
+// the point kernel's lane test needs one point per lane, so nine chunks in ten are read through their A streams
+// alone, a quarter of the bytes (round 4; before: one stream, lane l's four values at bit 4 b l).  A lane reads ONE
+// dword-aligned 8-byte (16-byte) load per axis and stream and shifts its data down by the 0..31 bits its first value
+// starts into that dword.  All A streams lie in one array, chunk after chunk (x, y, z), all B streams in another.
 // hdr[2 c] = {base x, base y, base z, bx | by << 6 | bz << 12 | kPackWideFlag if some b is 32},
-// hdr[2 c + 1] = {first 32-byte unit (lo, hi), lane spread of the chunk (fp32 bits, see Cloud::spread), 0}.
-// The buffer ends with spare bytes (the last lanes' 16-byte loads run past their values).
+// hdr[2 c + 1] = {first 32-byte unit (lo, hi) -- the chunk's A streams start 8 bytes x that into the A array, its B
+// streams 24 bytes x that into the B array --, lane spread of the chunk (fp32 bits, see Cloud::spread), 0}.
+// Both arrays end with spare bytes (the last lanes' loads run past their values).
 // Spatially ordered clouds need 16-21 bits per coordinate (neighbours share sign, exponent and leading
 // mantissa bits): 5-8 B/pt instead of 12 (round 2 stored whole bytes: 6.5-9.2 B/pt).
-constexpr uint32_t kPackMaxBits = 25;  // shift (<= 28) + 4 b <= 128 bits of a lane's load
+constexpr uint32_t kPackMaxBits = 25;  // shift (<= 31) + b <= 64, + 3 b <= 128 bits of a lane's two loads
 constexpr uint32_t kPackWideFlag = 1u << 18;
 struct PackedXyz {
     const uint4 *hdr;        // null: not packed
-    const uint32_t *planes;
+    const uint32_t *planes;  // the A streams (every lane's first value); one allocation with ...
+    const uint32_t *planes_b;  // ... the B streams (the other three values), pack_b_dwords(units) dwords behind
 };
+// where the B streams start inside the allocation, in dwords (units: 32-byte units of both streams together, the sum of
+// the chunks' axis widths; the A streams end with 64 spare bytes), and the allocation's size
+constexpr uint64_t pack_b_dwords(uint64_t units) { return (units * 2 + 16 + 15) & ~15ull; }
+constexpr uint64_t pack_total_dwords(uint64_t units) { return pack_b_dwords(units) + units * 6 + 16; }
 
 struct Cloud {
     const float *x, *y, *z;  // SoA, padded to a multiple of 4 points with NaN
@@ -242,8 +251,8 @@ void launch_chunk_bounds(hipStream_t s, const Cloud &c, float *bounds, float *sp
 // scan) and *total_planes (device; in 32-byte units); pack_write fills the blocks; pack_verify counts the points whose decoded
 // coordinates differ from the raw ones (must be 0) into *mismatches (device).  nchunks = ceil(ceil(n / 4) / 64).
 void pack_measure(hipStream_t s, const Cloud &c, uint4 *hdr, uint32_t *chunk_planes, uint64_t *total_planes);  // (c.spread -> hdr[2 c + 1].z)
-void pack_write(hipStream_t s, const Cloud &c, const uint4 *hdr, uint32_t *planes);
-void pack_verify(hipStream_t s, const Cloud &c, const uint4 *hdr, const uint32_t *planes, uint64_t *mismatches);
+void pack_write(hipStream_t s, const Cloud &c, const uint4 *hdr, uint32_t *planes, uint32_t *planes_b);
+void pack_verify(hipStream_t s, const Cloud &c, const uint4 *hdr, const uint32_t *planes, const uint32_t *planes_b, uint64_t *mismatches);
 // x, y, z (padded to a multiple of 4 points) back from the packed form, bit for bit
 void unpack_to_soa(hipStream_t s, const PackedXyz &pk, uint64_t n, float *x, float *y, float *z);
 int reorder_morton(hipStream_t s, float *x, float *y, float *z, uint32_t *rgba, uint64_t n);  // rtr_reorder.hip

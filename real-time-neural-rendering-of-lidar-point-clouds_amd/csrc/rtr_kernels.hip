@@ -857,73 +857,92 @@ void launch_lean_fold(hipStream_t s, int W, int H, const TileStore &S, int parit
 }
 
 // PackedXyz helpers ---------------------------------------------------------------
-// An axis block is one little-endian bit stream: lane l's four b-bit values are bits [4 b l, 4 b l + 4 b), value k
-// at + b k.  A lane reads the 16 bytes that start at the DWORD holding its first bit (loads whose lane stride is not
-// a multiple of four bytes run at a third of the rate: 2.2-3.8 TB/s against 7.0, tools/align_probe.hip) and shifts
-// its data down by the remaining 0..28 bits; b <= 25 keeps shift + 4 b <= 128.  A fixed number of loads per chunk
-// (one per axis), no branch around any of them; the buffer ends with spare bytes for the last lane's over-read.
+// An axis block is TWO little-endian bit streams (rtr_kernels.h): the FIRST value of every lane -- lane l's b bits at bit
+// b l of the A stream, 8 b bytes -- and its other three -- 3 b bits at bit 3 b l of the B stream, 24 b bytes.  A lane
+// reads the 8 (16) bytes that start at the DWORD holding its first bit (loads whose lane stride is not a multiple of
+// four bytes run at a third of the rate: 2.2-3.8 TB/s against 7.0, tools/align_probe.hip) and shifts its data down by
+// the remaining 0..31 bits; b <= 25 keeps shift + b <= 64 and shift + 3 b <= 128.  A fixed number of loads per chunk,
+// no branch around any of them; both streams end with spare bytes for the last lane's over-read.
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+struct AxisRawA { uint32_t d[2]; };
 struct AxisRaw { uint32_t d[4]; };
-__device__ __forceinline__ AxisRaw ld_axis(const uint8_t *block, uint32_t b, int lane) {
-    const uint32_t dw = (b * (uint32_t)lane) >> 3;  // (4 b l) >> 5
+__device__ __forceinline__ AxisRawA ld_axis_a(const uint8_t *block, uint32_t b, int lane) {
+    const uint32_t dw = (b * (uint32_t)lane) >> 5;
+    const u32x2_a4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_a4 *>(block + 4u * dw));
+    return AxisRawA{{v.x, v.y}};
+}
+__device__ __forceinline__ AxisRaw ld_axis_b(const uint8_t *block, uint32_t b, int lane) {
+    const uint32_t dw = (3u * b * (uint32_t)lane) >> 5;
     const u32x4_a4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4 *>(block + 4u * dw));
     return AxisRaw{{v.x, v.y, v.z, v.w}};
 }
-// value k = base | bits [b k, b k + b) of the lane's realigned data.  Branch-free for every b <= 25 (b = 0: the mask is
-// empty and the value is the base): the lane's 128 bits are shifted down by its sub-dword offset (four v_alignbit
-// with a per-lane shift), then three more times by b, each time one dword less of it (3 + 2 + 1 v_alignbit with a
-// scalar shift); every value is the low dword of one of those, masked and OR-ed onto the base.  A first version
-// picked the dwords a value straddles by width class behind wave-uniform branches: ~10 branches per axis made the
-// point kernel 14 us slower than the byte-granular form it was meant to beat.  b is wave-uniform.
-__device__ __forceinline__ float4 unpack_axis_narrow(const AxisRaw &r, uint32_t b, uint32_t base, int lane) {
+// value 0 = base | the lane's b bits of the A stream, value k = base | bits [b (k - 1), b k) of its realigned B data.
+// Branch-free for every b <= 25 (b = 0: the mask is empty and the value is the base).  A first version picked the dwords
+// a value straddles by width class behind wave-uniform branches: ~10 branches per axis made the point kernel 14 us
+// slower than the byte-granular form it was meant to beat.  b is wave-uniform.
+__device__ __forceinline__ float4 unpack_axis_narrow(const AxisRawA &ra, const AxisRaw &r, uint32_t b, uint32_t base, int lane) {
     // (a VOP3 instruction reads at most one scalar register on gfx950: with mask AND base scalar the compiler splits every
     // v_and_or into two instructions; the base in a vector register keeps it one)
     uint32_t vbase = base;
     asm("" : "+v"(vbase));
-    const uint32_t sh = ((b * (uint32_t)lane) & 7u) << 2;  // (4 b l) & 31
-    const uint32_t mask = (1u << b) - 1u;                    // (b <= 25)
-    const uint32_t e0 = __builtin_amdgcn_alignbit(r.d[1], r.d[0], sh), e1 = __builtin_amdgcn_alignbit(r.d[2], r.d[1], sh);
-    const uint32_t e2 = __builtin_amdgcn_alignbit(r.d[3], r.d[2], sh), e3 = r.d[3] >> sh;
+    uint32_t sha, shb;  // (b l) & 31, (3 b l) & 31: alignbit takes the low five bits of its shift
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(sha) : "s"(b), "v"(lane));
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(shb) : "s"(3u * b), "v"(lane));
+    const uint32_t mask = (1u << b) - 1u;  // (b <= 25)
+    const uint32_t a0 = __builtin_amdgcn_alignbit(ra.d[1], ra.d[0], sha);
+    const uint32_t e0 = __builtin_amdgcn_alignbit(r.d[1], r.d[0], shb), e1 = __builtin_amdgcn_alignbit(r.d[2], r.d[1], shb);
+    const uint32_t e2 = __builtin_amdgcn_alignbit(r.d[3], r.d[2], shb);
     const uint32_t f0 = __builtin_amdgcn_alignbit(e1, e0, b), f1 = __builtin_amdgcn_alignbit(e2, e1, b);
-    const uint32_t f2 = __builtin_amdgcn_alignbit(e3, e2, b);
-    const uint32_t g0 = __builtin_amdgcn_alignbit(f1, f0, b), g1 = __builtin_amdgcn_alignbit(f2, f1, b);
-    const uint32_t h0 = __builtin_amdgcn_alignbit(g1, g0, b);
+    const uint32_t g0 = __builtin_amdgcn_alignbit(f1, f0, b);
     auto and_or = [&](uint32_t e) -> float {  // (the compiler leaves v_and + v_or here)
         uint32_t x;
         asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(x) : "v"(e), "s"(mask), "v"(vbase));
         return __uint_as_float(x);
     };
-    return make_float4(and_or(e0), and_or(f0), and_or(g0), and_or(h0));
+    return make_float4(and_or(a0), and_or(e0), and_or(f0), and_or(g0));
 }
-__device__ __forceinline__ float4 unpack_axis(const AxisRaw &r, uint32_t b, uint32_t base, int lane) {
-    if (b == 32u)  // (lane l's four values are its four dwords)
-        return make_float4(__uint_as_float(r.d[0]), __uint_as_float(r.d[1]), __uint_as_float(r.d[2]), __uint_as_float(r.d[3]));
-    return unpack_axis_narrow(r, b, base, lane);
+__device__ __forceinline__ float4 unpack_axis(const AxisRawA &ra, const AxisRaw &r, uint32_t b, uint32_t base, int lane) {
+    if (b == 32u)  // (lane l's first value is dword l of the A stream, its other three dwords 3 l .. 3 l + 2 of the B stream)
+        return make_float4(__uint_as_float(ra.d[0]), __uint_as_float(r.d[0]), __uint_as_float(r.d[1]), __uint_as_float(r.d[2]));
+    return unpack_axis_narrow(ra, r, b, base, lane);
 }
+struct ChunkRawA { AxisRawA a[3]; };
 struct ChunkRaw { AxisRaw a[3]; };
-__device__ __forceinline__ ChunkRaw load_chunk(const uint32_t *__restrict__ planes, const uint4 &h0, const uint4 &h1, int lane) {
-    const uint8_t *p = reinterpret_cast<const uint8_t *>(planes) + (((((uint64_t)h1.y) << 32) | (uint64_t)h1.x) << 5);
+__device__ __forceinline__ ChunkRawA load_chunk_a(const uint32_t *__restrict__ planes_a, const uint4 &h0, const uint4 &h1, int lane) {
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(planes_a) + (((((uint64_t)h1.y) << 32) | (uint64_t)h1.x) << 3);
+    ChunkRawA c;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const uint32_t b = (h0.w >> (6 * a)) & 63u;
+        c.a[a] = ld_axis_a(p, b, lane);
+        p += 8u * b;
+    }
+    return c;
+}
+__device__ __forceinline__ ChunkRaw load_chunk_b(const uint32_t *__restrict__ planes_b, const uint4 &h0, const uint4 &h1, int lane) {
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(planes_b) + (((((uint64_t)h1.y) << 32) | (uint64_t)h1.x) * 24u);
     ChunkRaw c;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const uint32_t b = (h0.w >> (6 * a)) & 63u;
-        c.a[a] = ld_axis(p, b, lane);
-        p += 32u * b;
+        c.a[a] = ld_axis_b(p, b, lane);
+        p += 24u * b;
     }
     return c;
 }
-__device__ __forceinline__ void unpack_chunk(const ChunkRaw &c, uint32_t widths, uint32_t bx, uint32_t by, uint32_t bz, float4 &X,
-                                             float4 &Y, float4 &Z, int lane) {
+__device__ __forceinline__ void unpack_chunk(const ChunkRawA &ca, const ChunkRaw &c, uint32_t widths, uint32_t bx, uint32_t by, uint32_t bz,
+                                             float4 &X, float4 &Y, float4 &Z, int lane) {
     if (!(widths & kPackWideFlag)) {  // no axis of the chunk needs all 32 bits (the usual case)
         // (a constant axis -- a wall of the synthetic room, 30 % of its axis blocks -- skips the fifteen instructions)
         const uint32_t wx = widths & 63u, wy = (widths >> 6) & 63u, wz = (widths >> 12) & 63u;
-        X = wx ? unpack_axis_narrow(c.a[0], wx, bx, lane) : make_float4(__uint_as_float(bx), __uint_as_float(bx), __uint_as_float(bx), __uint_as_float(bx));
-        Y = wy ? unpack_axis_narrow(c.a[1], wy, by, lane) : make_float4(__uint_as_float(by), __uint_as_float(by), __uint_as_float(by), __uint_as_float(by));
-        Z = wz ? unpack_axis_narrow(c.a[2], wz, bz, lane) : make_float4(__uint_as_float(bz), __uint_as_float(bz), __uint_as_float(bz), __uint_as_float(bz));
+        X = wx ? unpack_axis_narrow(ca.a[0], c.a[0], wx, bx, lane) : make_float4(__uint_as_float(bx), __uint_as_float(bx), __uint_as_float(bx), __uint_as_float(bx));
+        Y = wy ? unpack_axis_narrow(ca.a[1], c.a[1], wy, by, lane) : make_float4(__uint_as_float(by), __uint_as_float(by), __uint_as_float(by), __uint_as_float(by));
+        Z = wz ? unpack_axis_narrow(ca.a[2], c.a[2], wz, bz, lane) : make_float4(__uint_as_float(bz), __uint_as_float(bz), __uint_as_float(bz), __uint_as_float(bz));
     } else {
-        X = unpack_axis(c.a[0], widths & 63u, bx, lane);
-        Y = unpack_axis(c.a[1], (widths >> 6) & 63u, by, lane);
-        Z = unpack_axis(c.a[2], (widths >> 12) & 63u, bz, lane);
+        X = unpack_axis(ca.a[0], c.a[0], widths & 63u, bx, lane);
+        Y = unpack_axis(ca.a[1], c.a[1], (widths >> 6) & 63u, by, lane);
+        Z = unpack_axis(ca.a[2], c.a[2], (widths >> 12) & 63u, bz, lane);
     }
 }
 
@@ -1010,7 +1029,8 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
     const float *const spread = CULL ? nullptr : bounds;
     const bool lane_test = (clear_split & 4) == 0;
     const uint4 *const pk_hdr = reinterpret_cast<const uint4 *>(x4);
-    const uint32_t *const pk_planes = reinterpret_cast<const uint32_t *>(y4);
+    const uint32_t *const pk_planes = reinterpret_cast<const uint32_t *>(y4);    // the A streams
+    const uint32_t *const pk_planes_b = reinterpret_cast<const uint32_t *>(z4);  // the B streams
     const float fW = (float)W, fH = (float)H;
     const float hiW = f_add(fW, 0.25f), hiH = f_add(fH, 0.25f);
     const int lane = threadIdx.x & 63;
@@ -1096,9 +1116,9 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
     auto first_value = [&](uint32_t d0, uint32_t d1, uint32_t b, uint32_t base) -> float {
         uint32_t vbase = base, x;
         asm("" : "+v"(vbase));
-        uint32_t sh;  // 4 b l; alignbit takes its low five bits.  (Written out: the compiler drops the mask on b, then no
+        uint32_t sh;  // b l (the A stream); alignbit takes its low five bits.  (Written out: the compiler drops the mask on b, then no
                       // longer knows the factor to be small and emits the quarter-rate 32-bit multiply.)
-        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(sh) : "s"(b << 2), "v"(lane));
+        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(sh) : "s"(b), "v"(lane));
         const uint32_t e0 = __builtin_amdgcn_alignbit(d1, d0, sh);
         const uint32_t mask = (1u << b) - 1u;
         asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(x) : "v"(e0), "s"(mask), "v"(vbase));
@@ -1303,9 +1323,11 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
         // No branch depends on whether the wave still has a chunk: past its last one it re-reads the cloud's
         // last chunk with every lane masked (at most two wasted iterations per wave), so the compiler sees
         // straight-line code and waits for the chunk's three loads exactly once, where they are decoded.
-        ChunkRaw raw;
+        // The light path reads the chunk's A streams only (every lane's FIRST value: a quarter of the chunk); the B streams
+        // are requested when the lane test leaves a candidate lane.
+        ChunkRawA raw;
         uint4 h0, h1;
-        uint32_t hc = 0, bx = 0, by = 0, bz = 0, ww = 0, i = 0, spb = 0;
+        uint32_t hc = 0, bx = 0, by = 0, bz = 0, ww = 0, i = 0, spb = 0, off_lo = 0, off_hi = 0;
         bool hvalid = false, live = false;
         auto fetch_hdr = [&](uint32_t q) {
             const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(q < R ? chunk_of(q) : nchunks));
@@ -1314,12 +1336,12 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
             h0 = pk_hdr[2 * (size_t)hc];
             h1 = pk_hdr[2 * (size_t)hc + 1];
         };
-        auto fetch_planes = [&]() {  // of the chunk whose header has arrived
+        auto fetch_planes = [&]() {  // (the A streams) of the chunk whose header has arrived
             i = hc * 64u + (uint32_t)lane;
             live = hvalid && i < n4;
             i = i < n4 ? i : n4 - 1u;  // (masked lanes: any valid address for the colour load)
-            bx = h0.x, by = h0.y, bz = h0.z, ww = h0.w, spb = h1.z;
-            raw = load_chunk(pk_planes, h0, h1, lane);
+            bx = h0.x, by = h0.y, bz = h0.z, ww = h0.w, spb = h1.z, off_lo = h1.x, off_hi = h1.y;
+            raw = load_chunk_a(pk_planes, h0, h1, lane);
         };
         fetch_hdr(0);
         fetch_planes();
@@ -1333,8 +1355,8 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
             const uint32_t i_c = i;
             float4 X, Y, Z;
 #ifdef RTR_EXPERIMENT
-            if (RTR_XP(128)) {  // the stream alone: headers, planes, loop bookkeeping
-                xp_sink ^= raw.a[0].d[0] ^ raw.a[1].d[1] ^ raw.a[2].d[2] ^ raw.a[0].d[3] ^ raw.a[1].d[0] ^ raw.a[2].d[1];
+            if (RTR_XP(128)) {  // the stream alone: headers, A streams, loop bookkeeping
+                xp_sink ^= raw.a[0].d[0] ^ raw.a[1].d[1] ^ raw.a[2].d[0] ^ raw.a[0].d[1] ^ raw.a[1].d[0] ^ raw.a[2].d[1];
                 fetch_planes();
                 fetch_hdr(q + 2);
                 continue;
@@ -1350,7 +1372,9 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
                 cand = lane_maybe(x0, y0, z0, __uint_as_float(sp_c), live_c);
             }
             if (cand) {
-                unpack_chunk(raw, ww, bx, by, bz, X, Y, Z, lane);
+                const uint4 hc0 = make_uint4(bx, by, bz, ww), hc1 = make_uint4(off_lo, off_hi, 0u, 0u);
+                const ChunkRaw raw_b = load_chunk_b(pk_planes_b, hc0, hc1, lane);
+                unpack_chunk(raw, raw_b, ww, bx, by, bz, X, Y, Z, lane);
                 project_rows(X, Y, Z, r);
             }
             fetch_planes();
@@ -1452,8 +1476,9 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
                 if (PACKED) {
                     const uint32_t cc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(i >> 6));
                     const uint4 h0 = pk_hdr[2 * (size_t)cc], h1 = pk_hdr[2 * (size_t)cc + 1];
-                    const ChunkRaw raw = load_chunk(pk_planes, h0, h1, lane);
-                    unpack_chunk(raw, h0.w, h0.x, h0.y, h0.z, X, Y, Z, lane);
+                    const ChunkRawA raw_a = load_chunk_a(pk_planes, h0, h1, lane);
+                    const ChunkRaw raw = load_chunk_b(pk_planes_b, h0, h1, lane);
+                    unpack_chunk(raw_a, raw, h0.w, h0.x, h0.y, h0.z, X, Y, Z, lane);
                 } else {
                     X = ld_stream(x4 + ic), Y = ld_stream(y4 + ic), Z = ld_stream(z4 + ic);
                 }
@@ -2461,7 +2486,8 @@ void launch_project_bin(hipStream_t s, const Cloud &c, const Proj &P, int W, int
     const LaneTest lt = lane_test_consts(P, W, H, c.absmax);
     const dim3 block(kBlock);
     const float4 *x = packed ? (const float4 *)c.pk.hdr : (const float4 *)c.x;
-    const float4 *y = packed ? (const float4 *)c.pk.planes : (const float4 *)c.y, *z = (const float4 *)c.z;
+    const float4 *y = packed ? (const float4 *)c.pk.planes : (const float4 *)c.y;
+    const float4 *z = packed ? (const float4 *)c.pk.planes_b : (const float4 *)c.z;
     const uint4 *col = (const uint4 *)c.rgba;
     // The default grid is what is RESIDENT at once (the kernel is a grid-stride loop over windows of the cloud: a
     // workgroup that has to wait for a slot runs the whole loop as a second round).  A packed chunk is ~1.3 KB in flight
@@ -2622,50 +2648,63 @@ __global__ __launch_bounds__(512) void k_pack_scan(const uint32_t *__restrict__ 
 }
 __global__ __launch_bounds__(kBlock) void k_pack_write(const uint4 *__restrict__ x4, const uint4 *__restrict__ y4,
                                                        const uint4 *__restrict__ z4, uint64_t n4, const uint4 *__restrict__ hdr,
-                                                       uint32_t *__restrict__ planes) {
-    // (a one-off at upload.)  An axis block is assembled in LDS -- every lane ORs its 4 b bits in at bit 4 b l --
-    // and leaves as whole dwords, coalesced.
-    __shared__ uint32_t s_blk[kBlock / 64][256 + 4];
+                                                       uint32_t *__restrict__ planes_a, uint32_t *__restrict__ planes_b) {
+    // (a one-off at upload.)  The two streams of an axis block are assembled in LDS -- every lane ORs its first value in
+    // at bit b l of the A stream and its other three at bit 3 b l of the B stream -- and leave as whole dwords, coalesced.
+    __shared__ uint32_t s_blk[kBlock / 64][256 + 8];
     const uint64_t nchunks = (n4 + 63) / 64;
     const int lane = threadIdx.x & 63;
-    uint32_t *const blk = s_blk[threadIdx.x >> 6];
+    uint32_t *const blk_a = s_blk[threadIdx.x >> 6], *const blk_b = blk_a + 64 + 4;  // (A: <= 64 dwords, B: <= 192)
     for (uint64_t c = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6; c < nchunks; c += ((uint64_t)gridDim.x * kBlock) >> 6) {
         uint32_t v[3][4];
         chunk_bits(x4, y4, z4, n4, c, lane, v);
         const uint4 h0 = hdr[2 * c], h1 = hdr[2 * c + 1];
-        uint32_t *p = planes + (((((uint64_t)h1.y) << 32) | (uint64_t)h1.x) << 3);
+        const uint64_t off = (((uint64_t)h1.y) << 32) | (uint64_t)h1.x;  // 32-byte units over both streams
+        uint32_t *pa = planes_a + off * 2, *pb = planes_b + off * 6;
 #pragma unroll 1
         for (int a = 0; a < 3; ++a) {
             const uint32_t b = (h0.w >> (6 * a)) & 63u;  // wave-uniform
             if (b == 0u) continue;
-            const uint32_t ndw = 8u * b;  // dwords of the block
-            for (uint32_t j = (uint32_t)lane; j < ndw + 4u; j += 64u) blk[j] = 0u;
+            const uint32_t ndw_a = 2u * b, ndw_b = 6u * b;  // dwords of the two streams
+            for (uint32_t j = (uint32_t)lane; j < ndw_a + 2u; j += 64u) blk_a[j] = 0u;
+            for (uint32_t j = (uint32_t)lane; j < ndw_b + 4u; j += 64u) blk_b[j] = 0u;
             __builtin_amdgcn_wave_barrier();
-            unsigned __int128 blob = 0;
             const uint32_t m = b == 32u ? 0xFFFFFFFFu : ((1u << b) - 1u);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) blob |= (unsigned __int128)(v[a][k] & m) << (b * (uint32_t)k);
-            const uint32_t bit = 4u * b * (uint32_t)lane, dw = bit >> 5, sh = bit & 31u;
-            // (the blob, shifted by sh < 32 bits, spans at most five dwords)
-            const uint32_t lo32[4] = {(uint32_t)blob, (uint32_t)(blob >> 32), (uint32_t)(blob >> 64), (uint32_t)(blob >> 96)};
-            uint32_t carry = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t w = (lo32[j] << sh) | carry;
-                carry = sh ? (lo32[j] >> (32u - sh)) : 0u;
-                if (w) atomicOr(&blk[dw + j], w);
+            {  // first value
+                const uint32_t bit = b * (uint32_t)lane, dw = bit >> 5, sh = bit & 31u;
+                const unsigned long long w = (unsigned long long)(v[a][0] & m) << sh;
+                if ((uint32_t)w) atomicOr(&blk_a[dw], (uint32_t)w);
+                if ((uint32_t)(w >> 32)) atomicOr(&blk_a[dw + 1], (uint32_t)(w >> 32));
             }
-            if (carry) atomicOr(&blk[dw + 4], carry);
+            {  // the other three
+                unsigned __int128 blob = 0;
+#pragma unroll
+                for (int k = 1; k < 4; ++k) blob |= (unsigned __int128)(v[a][k] & m) << (b * (uint32_t)(k - 1));
+                const uint32_t bit = 3u * b * (uint32_t)lane, dw = bit >> 5, sh = bit & 31u;
+                // (the blob, 3 b <= 96 bits, shifted by sh < 32 bits, spans at most four dwords)
+                const uint32_t lo32[3] = {(uint32_t)blob, (uint32_t)(blob >> 32), (uint32_t)(blob >> 64)};
+                uint32_t carry = 0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const uint32_t w = (lo32[j] << sh) | carry;
+                    carry = sh ? (lo32[j] >> (32u - sh)) : 0u;
+                    if (w) atomicOr(&blk_b[dw + j], w);
+                }
+                if (carry) atomicOr(&blk_b[dw + 3], carry);
+            }
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t j = (uint32_t)lane; j < ndw; j += 64u) p[j] = blk[j];
+            for (uint32_t j = (uint32_t)lane; j < ndw_a; j += 64u) pa[j] = blk_a[j];
+            for (uint32_t j = (uint32_t)lane; j < ndw_b; j += 64u) pb[j] = blk_b[j];
             __builtin_amdgcn_wave_barrier();
-            p += ndw;
+            pa += ndw_a;
+            pb += ndw_b;
         }
     }
 }
 __global__ __launch_bounds__(kBlock) void k_pack_verify(const uint4 *__restrict__ x4, const uint4 *__restrict__ y4,
                                                         const uint4 *__restrict__ z4, uint64_t n4, const uint4 *__restrict__ hdr,
-                                                        const uint32_t *__restrict__ planes, unsigned long long *mismatches) {
+                                                        const uint32_t *__restrict__ planes, const uint32_t *__restrict__ planes_b,
+                                                        unsigned long long *mismatches) {
     const uint64_t nchunks = (n4 + 63) / 64;
     const int lane = threadIdx.x & 63;
     unsigned long long bad = 0;
@@ -2673,9 +2712,10 @@ __global__ __launch_bounds__(kBlock) void k_pack_verify(const uint4 *__restrict_
         uint32_t v[3][4];
         chunk_bits(x4, y4, z4, n4, c, lane, v);
         const uint4 h0 = hdr[2 * c], h1 = hdr[2 * c + 1];
-        const ChunkRaw raw = load_chunk(planes, h0, h1, lane);
+        const ChunkRawA raw_a = load_chunk_a(planes, h0, h1, lane);
+        const ChunkRaw raw = load_chunk_b(planes_b, h0, h1, lane);
         float4 X, Y, Z;
-        unpack_chunk(raw, h0.w, h0.x, h0.y, h0.z, X, Y, Z, lane);
+        unpack_chunk(raw_a, raw, h0.w, h0.x, h0.y, h0.z, X, Y, Z, lane);
         const uint32_t got[3][4] = {{__float_as_uint(X.x), __float_as_uint(X.y), __float_as_uint(X.z), __float_as_uint(X.w)},
                                     {__float_as_uint(Y.x), __float_as_uint(Y.y), __float_as_uint(Y.z), __float_as_uint(Y.w)},
                                     {__float_as_uint(Z.x), __float_as_uint(Z.y), __float_as_uint(Z.z), __float_as_uint(Z.w)}};
@@ -2689,15 +2729,17 @@ __global__ __launch_bounds__(kBlock) void k_pack_verify(const uint4 *__restrict_
 // the SoA arrays back from the packed form (bit for bit: the form is lossless) -- for the calls that read fp32
 // coordinates when the context keeps only the packed form resident (rtr_api.hip, ensure_soa)
 __global__ __launch_bounds__(kBlock) void k_unpack_soa(const uint4 *__restrict__ hdr, const uint32_t *__restrict__ planes,
+                                                       const uint32_t *__restrict__ planes_b,
                                                        uint64_t n4, float4 *__restrict__ x4, float4 *__restrict__ y4,
                                                        float4 *__restrict__ z4) {
     const uint64_t nchunks = (n4 + 63) / 64;
     const int lane = threadIdx.x & 63;
     for (uint64_t c = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6; c < nchunks; c += ((uint64_t)gridDim.x * kBlock) >> 6) {
         const uint4 h0 = hdr[2 * c], h1 = hdr[2 * c + 1];
-        const ChunkRaw raw = load_chunk(planes, h0, h1, lane);
+        const ChunkRawA raw_a = load_chunk_a(planes, h0, h1, lane);
+        const ChunkRaw raw = load_chunk_b(planes_b, h0, h1, lane);
         float4 X, Y, Z;
-        unpack_chunk(raw, h0.w, h0.x, h0.y, h0.z, X, Y, Z, lane);
+        unpack_chunk(raw_a, raw, h0.w, h0.x, h0.y, h0.z, X, Y, Z, lane);
         const uint64_t i = c * 64 + lane;
         if (i < n4) x4[i] = X, y4[i] = Y, z4[i] = Z;
     }
@@ -2714,23 +2756,23 @@ void pack_measure(hipStream_t s, const Cloud &c, uint4 *hdr, uint32_t *chunk_pla
                        (const uint4 *)c.z, n4, hdr, chunk_planes);
     hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(512), 0, s, chunk_planes, (n4 + 63) / 64, hdr, total_planes, c.spread);
 }
-void pack_write(hipStream_t s, const Cloud &c, const uint4 *hdr, uint32_t *planes) {
+void pack_write(hipStream_t s, const Cloud &c, const uint4 *hdr, uint32_t *planes, uint32_t *planes_b) {
     const uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) return;
     hipLaunchKernelGGL(k_pack_write, dim3(pack_grid(n4)), dim3(kBlock), 0, s, (const uint4 *)c.x, (const uint4 *)c.y,
-                       (const uint4 *)c.z, n4, hdr, planes);
+                       (const uint4 *)c.z, n4, hdr, planes, planes_b);
 }
-void pack_verify(hipStream_t s, const Cloud &c, const uint4 *hdr, const uint32_t *planes, uint64_t *mismatches) {
+void pack_verify(hipStream_t s, const Cloud &c, const uint4 *hdr, const uint32_t *planes, const uint32_t *planes_b, uint64_t *mismatches) {
     const uint64_t n4 = (c.n + 3) / 4;
     if (n4 == 0) return;
     hipLaunchKernelGGL(k_pack_verify, dim3(pack_grid(n4)), dim3(kBlock), 0, s, (const uint4 *)c.x, (const uint4 *)c.y,
-                       (const uint4 *)c.z, n4, hdr, planes, (unsigned long long *)mismatches);
+                       (const uint4 *)c.z, n4, hdr, planes, planes_b, (unsigned long long *)mismatches);
 }
 
 void unpack_to_soa(hipStream_t s, const PackedXyz &pk, uint64_t n, float *x, float *y, float *z) {
     const uint64_t n4 = (n + 3) / 4;
     if (n4 == 0) return;
-    hipLaunchKernelGGL(k_unpack_soa, dim3(pack_grid(n4)), dim3(kBlock), 0, s, pk.hdr, pk.planes, n4, (float4 *)x, (float4 *)y, (float4 *)z);
+    hipLaunchKernelGGL(k_unpack_soa, dim3(pack_grid(n4)), dim3(kBlock), 0, s, pk.hdr, pk.planes, pk.planes_b, n4, (float4 *)x, (float4 *)y, (float4 *)z);
 }
 
 void launch_tile(hipStream_t s, int mode, int W, int H, const TileStore &S, float window, uint32_t *depth,
