@@ -38,8 +38,8 @@ struct PackedXyz {
     const uint32_t *planes_b;  // ... the B streams (the other three values), pack_b_dwords(units) dwords behind
 };
 // where the B streams start inside the allocation, in dwords (units: 32-byte units of both streams together, the sum of
-// the chunks' axis widths; the A streams end with 64 spare bytes), and the allocation's size
-constexpr uint64_t pack_b_dwords(uint64_t units) { return (units * 2 + 16 + 15) & ~15ull; }
+// the chunks' axis widths; the A streams end with ~1 KB of spare bytes), and the allocation's size
+constexpr uint64_t pack_b_dwords(uint64_t units) { return (units * 2 + 256 + 16 + 15) & ~15ull; }  // (the point kernel requests 1 KB per chunk)
 constexpr uint64_t pack_total_dwords(uint64_t units) { return pack_b_dwords(units) + units * 6 + 16; }
 
 struct Cloud {

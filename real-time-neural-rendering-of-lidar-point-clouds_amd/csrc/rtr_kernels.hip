@@ -371,6 +371,12 @@ constexpr int kTileThreadsCompact = RTR_TILE0_THREADS;  // k_tile<0> (see tile_b
 #define RTR_TILE0_BATCH 8
 #endif
 constexpr int kTileBatch = RTR_TILE_BATCH;    // entries in flight per thread in k_tile
+#ifndef RTR_T1_RING
+#define RTR_T1_RING 3  // the packed point kernel's LDS ring: chunks of A streams in flight per wave (k_project_bin)
+#endif
+#ifndef RTR_T1_LEAD
+#define RTR_T1_LEAD 4  // ... and how many iterations a chunk's header is requested ahead of its A streams
+#endif
 #ifndef RTR_T1_WAVES
 #define RTR_T1_WAVES 5  // the packed point kernel: five waves per SIMD (96 registers, four of them spilled to scratch in the
 #endif                  // long path only; round 4: 126-129 us against 127-133 at four, six -- 80 registers, 51 spilled -- 180);
@@ -1325,61 +1331,118 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
         // straight-line code and waits for the chunk's three loads exactly once, where they are decoded.
         // The light path reads the chunk's A streams only (every lane's FIRST value: a quarter of the chunk); the B streams
         // are requested when the lane test leaves a candidate lane.
-        ChunkRawA raw;
-        uint4 h0, h1;
-        uint32_t hc = 0, bx = 0, by = 0, bz = 0, ww = 0, i = 0, spb = 0, off_lo = 0, off_hi = 0;
-        bool hvalid = false, live = false;
-        auto fetch_hdr = [&](uint32_t q) {
-            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(q < R ? chunk_of(q) : nchunks));
-            hvalid = c < nchunks;
-            hc = hvalid ? c : nchunks - 1u;
-            h0 = pk_hdr[2 * (size_t)hc];
-            h1 = pk_hdr[2 * (size_t)hc + 1];
+        //
+        // THE RING.  With a quarter of the bytes per chunk the loop is no longer near HBM's rate but bound by its own
+        // chain -- one chunk in flight per wave, one memory round trip per iteration (T1 112-117 us against 119-122: 60 %
+        // fewer bytes bought 6 %).  So the A streams of the next kRing chunks are in flight at once, and in no register:
+        // a chunk's A streams are one contiguous piece of at most 768 bytes, which ONE global_load_lds_dwordx4 (16 bytes
+        // per lane, 1 KB per wave) lands in an LDS slot of the wave; the headers travel the same way (two lanes' worth,
+        // 32 bytes), two chunks further ahead, because a chunk's data request needs the offset its header holds -- so
+        // no header lives in scalar registers any more, and no scalar load's latency sits on the LDS reads' counter.
+        // Iteration q: request header q + kRing + kLead; header q + kRing has landed (vmcnt(2 kLead): the requests return in
+        // order, two per iteration) -> request its data into the slot chunk q - 1 has left; data q has landed (vmcnt(2 kRing))
+        // -> read header and data q out of their slots.  The compiler knows nothing of these requests (inline assembly):
+        // every wait for them is written here; its own waits for ordinary loads (the long path's B streams, colours,
+        // claims) drain them too, which is only conservative.
+        // The loop is bound by the instructions it issues -- the scalar unit is shared by a CU's twenty waves -- so the
+        // ring sizes are powers of two, the chunk id runs along incrementally, and addresses are scalar base + lane offset.
+        constexpr int kRing = RTR_T1_RING, kLead = RTR_T1_LEAD, kRingH = kRing + kLead;  // (kLead: iterations a header is ahead of its data)
+        static_assert(((kRing + 1) & kRing) == 0 && ((kRingH + 1) & kRingH) == 0, "ring sizes: powers of two");
+        typedef uint32_t __attribute__((address_space(3))) lds_u32;
+        constexpr int kSlotDw = 256;  // (a chunk's A streams: <= 768 bytes; 48 lanes request 16 bytes each)
+        __shared__ __attribute__((aligned(16))) uint32_t s_ring[kBlock / 64][kRing + 1][kSlotDw];  // data
+        __shared__ __attribute__((aligned(16))) uint32_t s_rhdr[kBlock / 64][kRingH + 1][8];       // headers
+        const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32 *)s_ring[threadIdx.x >> 6]);
+        const uint32_t rhdr_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32 *)s_rhdr[threadIdx.x >> 6]);
+        const uint32_t lane16 = 16u * (uint32_t)lane;
+        // chunk of position q, incrementally: c(q + 1) = c(q) + NW, back to the wave's first chunk when the round wraps
+        const uint32_t c_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(phase * NW + wave)), c_wrap = R * NW + wave;
+        auto next_chunk = [&](uint32_t c) -> uint32_t {
+            c += NW;
+            return c >= c_wrap ? c - R * NW : c;
         };
-        auto fetch_planes = [&]() {  // (the A streams) of the chunk whose header has arrived
-            i = hc * 64u + (uint32_t)lane;
-            live = hvalid && i < n4;
-            i = i < n4 ? i : n4 - 1u;  // (masked lanes: any valid address for the colour load)
-            bx = h0.x, by = h0.y, bz = h0.z, ww = h0.w, spb = h1.z, off_lo = h1.x, off_hi = h1.y;
-            raw = load_chunk_a(pk_planes, h0, h1, lane);
+        auto req_hdr = [&](uint32_t q, uint32_t c) {  // (c: position q's chunk; past the cloud's end: its last chunk, masked later)
+            const uint32_t cc = c < nchunks ? c : nchunks - 1u;
+            const uint32_t voff = 32u * cc + lane16, lds = rhdr_lds + 32u * (q & (uint32_t)kRingH);
+            if (lane < 2) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(pk_hdr), "s"(lds) : "memory");
         };
-        fetch_hdr(0);
-        fetch_planes();
-        fetch_hdr(1);
+        auto req_data = [&](uint32_t q) {  // position q's header has landed
+            const lds_u32 *const hs = (const lds_u32 *)(uintptr_t)(rhdr_lds + 32u * (q & (uint32_t)kRingH));
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)hs[4]), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hs[5]);
+            const uint8_t *src = reinterpret_cast<const uint8_t *>(pk_planes) + (((((uint64_t)hi) << 32) | (uint64_t)lo) << 3);
+            const uint32_t lds = ring_lds + 4u * (uint32_t)kSlotDw * (q & (uint32_t)kRing);
+            if (lane < 48) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane16), "s"(src), "s"(lds) : "memory");
+        };
+        // (prologue: two drains, ~2 us once per launch, so that every wait below may count two requests per iteration)
+        uint32_t c_req = c_first;
+#pragma unroll
+        for (int k = 0; k < kRingH; ++k) {
+            req_hdr((uint32_t)k, (uint32_t)k < R ? c_req : nchunks);
+            c_req = next_chunk(c_req);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < kRing; ++k) req_data((uint32_t)k);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef RTR_EXPERIMENT
         uint32_t xp_sink = 0;
 #endif
+        uint32_t c_use = c_first;
         for (uint32_t q = 0; q < R; ++q) {
+            req_hdr(q + (uint32_t)kRingH, q + (uint32_t)kRingH < R ? c_req : nchunks);
+            c_req = next_chunk(c_req);
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * kLead) : "memory");  // header q + kRing (requested kLead iterations ago, or drained)
+            req_data(q + (uint32_t)kRing);
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * kRing) : "memory");  // data q (requested kRing iterations ago, or drained)
+            const lds_u32 *const slot = (const lds_u32 *)(uintptr_t)(ring_lds + 4u * (uint32_t)kSlotDw * (q & (uint32_t)kRing));
+            const lds_u32 *const hs = (const lds_u32 *)(uintptr_t)(rhdr_lds + 32u * (q & (uint32_t)kRingH));
+            typedef uint32_t u32x4_l __attribute__((ext_vector_type(4)));
+            const u32x4_l g0 = *reinterpret_cast<const u32x4_l __attribute__((address_space(3))) *>(hs);
+            const u32x4_l g1 = *reinterpret_cast<const u32x4_l __attribute__((address_space(3))) *>(hs + 4);
+            const uint32_t ww = (uint32_t)__builtin_amdgcn_readfirstlane((int)g0.w);
+            const uint32_t bx = g0.x, by = g0.y, bz = g0.z;  // (vector registers: they are only ever OR-ed into values)
+            const uint32_t cq = c_use < nchunks ? (c_use | 0x80000000u) : nchunks - 1u;
+            c_use = next_chunk(c_use);
+            const uint32_t wx = ww & 63u, wy = (ww >> 6) & 63u, wz = (ww >> 12) & 63u;
+            // the lane's two dwords of each A stream
+            ChunkRawA raw;
+            {
+                const uint32_t ix = (wx * (uint32_t)lane) >> 5, iy = 2u * wx + ((wy * (uint32_t)lane) >> 5);
+                const uint32_t iz = 2u * (wx + wy) + ((wz * (uint32_t)lane) >> 5);
+                raw.a[0].d[0] = slot[ix], raw.a[0].d[1] = slot[ix + 1];
+                raw.a[1].d[0] = slot[iy], raw.a[1].d[1] = slot[iy + 1];
+                raw.a[2].d[0] = slot[iz], raw.a[2].d[1] = slot[iz + 1];
+            }
+            uint32_t i_c = (cq & 0x7FFFFFFFu) * 64u + (uint32_t)lane;
+            const bool live_c = (cq >> 31) != 0u && i_c < n4;
+            i_c = i_c < n4 ? i_c : n4 - 1u;  // (masked lanes: any valid address for the colour load)
             Rows r;
-            const bool live_c = live;
-            const uint32_t i_c = i;
             float4 X, Y, Z;
 #ifdef RTR_EXPERIMENT
             if (RTR_XP(128)) {  // the stream alone: headers, A streams, loop bookkeeping
                 xp_sink ^= raw.a[0].d[0] ^ raw.a[1].d[1] ^ raw.a[2].d[0] ^ raw.a[0].d[1] ^ raw.a[1].d[0] ^ raw.a[2].d[1];
-                fetch_planes();
-                fetch_hdr(q + 2);
                 continue;
             }
 #endif
             // lane test: one point per lane; (wave-uniform) chunks with a 32-bit axis or without a finite spread skip it
             bool cand = true;
-            const uint32_t sp_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)spb);
+            const uint32_t sp_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)g1.z);
             if (lane_test && !(ww & kPackWideFlag) && sp_c < 0x7F000000u) {
-                const float x0 = first_value(raw.a[0].d[0], raw.a[0].d[1], ww & 63u, bx);
-                const float y0 = first_value(raw.a[1].d[0], raw.a[1].d[1], (ww >> 6) & 63u, by);
-                const float z0 = first_value(raw.a[2].d[0], raw.a[2].d[1], (ww >> 12) & 63u, bz);
+                const float x0 = first_value(raw.a[0].d[0], raw.a[0].d[1], wx, bx);
+                const float y0 = first_value(raw.a[1].d[0], raw.a[1].d[1], wy, by);
+                const float z0 = first_value(raw.a[2].d[0], raw.a[2].d[1], wz, bz);
                 cand = lane_maybe(x0, y0, z0, __uint_as_float(sp_c), live_c);
             }
-            if (cand) {
-                const uint4 hc0 = make_uint4(bx, by, bz, ww), hc1 = make_uint4(off_lo, off_hi, 0u, 0u);
+            if (!cand) continue;
+            {
+                const uint32_t sbx = (uint32_t)__builtin_amdgcn_readfirstlane((int)bx), sby = (uint32_t)__builtin_amdgcn_readfirstlane((int)by);
+                const uint32_t sbz = (uint32_t)__builtin_amdgcn_readfirstlane((int)bz);
+                const uint4 hc0 = make_uint4(sbx, sby, sbz, ww);
+                const uint4 hc1 = make_uint4((uint32_t)__builtin_amdgcn_readfirstlane((int)g1.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)g1.y), 0u, 0u);
                 const ChunkRaw raw_b = load_chunk_b(pk_planes_b, hc0, hc1, lane);
-                unpack_chunk(raw, raw_b, ww, bx, by, bz, X, Y, Z, lane);
+                unpack_chunk(raw, raw_b, ww, sbx, sby, sbz, X, Y, Z, lane);
                 project_rows(X, Y, Z, r);
             }
-            fetch_planes();
-            fetch_hdr(q + 2);
-            if (!cand) continue;
 #ifdef RTR_EXPERIMENT
             if (RTR_XP(256)) {  // ... + decode + the three matrix rows
                 xp_sink ^= __float_as_uint(r.rz[0]) ^ __float_as_uint(r.rz[1]) ^ __float_as_uint(r.rz[2]) ^ __float_as_uint(r.rz[3]);
@@ -1388,8 +1451,9 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
 #endif
             do_quad(i_c, live_c, r);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the requests past the wave's last chunk: into LDS, before it is left)
 #ifdef RTR_EXPERIMENT
-        if (xp_sink == 0x12345678u && live) fill[0] = 0u;  // practically never; keeps the work alive
+        if (xp_sink == 0x12345678u) fill[0] = 0u;  // practically never; keeps the work alive
 #endif
 
     } else if (!CULL) {
