@@ -132,11 +132,19 @@ def frame_bytes(n_local, W, H, with_filter):
 
 
 def moved_bytes_model(stream_bpp, n_local, stats):
-    """Bytes the point kernel moves per launch, from what it does: the resident coordinate stream (fp32 SoA 12 B/pt,
-    or the lossless packed form, headers included), 1 KiB of colours for every 256-point chunk that holds an
+    """Bytes the point kernel moves per launch, from what it does: the coordinate stream (fp32 SoA 12 B/pt; of the
+    lossless packed form what the kernel reads of it, see below), 1 KiB of colours for every 256-point chunk that holds an
     in-frustum point, 8 bytes written per in-frustum entry.  `stats` = frame statistics averaged over frames of the
     timed poses (rtr_frame_stats: entries, colour chunks); None for the atomic form, which streams xyz only."""
-    b = stream_bpp * n_local
+    if stats and stream_bpp < 11.9:
+        # packed form, two streams per axis (round 4): every chunk's header (32 B per 256 points) and A streams -- the
+        # first value of every lane, a quarter of the planes -- are read; the B streams only by the chunks that go on to
+        # the long path, counted here by the chunks WITH an in-frustum point (the candidates the per-point tests then
+        # reject are not counted: a lower bound, so the roofline fraction it gives errs low)
+        planes = stream_bpp - 0.125
+        b = n_local * (0.125 + planes / 4.0) + stats["colour_chunks"] * 256.0 * planes * 0.75
+    else:
+        b = stream_bpp * n_local
     if stats:
         b += 1024.0 * stats["colour_chunks"] + 8.0 * stats["entries"]
     return b

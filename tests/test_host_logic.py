@@ -171,7 +171,9 @@ def test_bench_roofline_fields():
     assert r["bytes_source"] == "pmc" and r["bytes_per_launch"] == 761_000_000.0 and r["traffic"] == 761_000_000
     assert abs(r["achieved"] - 761e6 / 0.150e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
     assert r["frac"] < 1.0 < r["vs_fp32_stream"] and abs(r["vs_fp32_stream"] - 12.0 * n / 0.150e-3 / 1e9 / 8000.0) < 1e-12
-    assert abs(r["bytes_model"] - (6.461 * n + 1024.0 * 60_000 + 8.0 * 6.8e6)) < 1 and r["limiter"] == "latency"
+    # (packed form, two streams per axis: headers + a quarter of the planes for every chunk, the rest for the long chunks)
+    model = n * (0.125 + (6.461 - 0.125) / 4.0) + 60_000 * 256.0 * (6.461 - 0.125) * 0.75 + 1024.0 * 60_000 + 8.0 * 6.8e6
+    assert abs(r["bytes_model"] - model) < 1 and r["limiter"] == "latency"
     assert r["algorithmic_bytes_per_launch"] == 12.0 * n and r["launches_timed"] == 25
     m = b.roofline_of(0.150, 25, n, None, 4, stream_bpp=6.461, stats=stats)  # not the profiled workload: the model
     assert m["bytes_source"] == "model" and m["traffic"] is None and m["bytes_per_launch"] == m["bytes_model"]
