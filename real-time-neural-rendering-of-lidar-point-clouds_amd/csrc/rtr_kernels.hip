@@ -1118,18 +1118,6 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
         const bool out = (int)(f_sub(rz0, sz) > lt.zsafe) & (int)(m < -f_mul(sp, lt.lall));  // (no branch)
         return __ballot(front && !out) != 0ull;
     };
-    // a lane's first value of an axis block (b <= 25; b = 0: the mask is empty, the value is the base)
-    auto first_value = [&](uint32_t d0, uint32_t d1, uint32_t b, uint32_t base) -> float {
-        uint32_t vbase = base, x;
-        asm("" : "+v"(vbase));
-        uint32_t sh;  // b l (the A stream); alignbit takes its low five bits.  (Written out: the compiler drops the mask on b, then no
-                      // longer knows the factor to be small and emits the quarter-rate 32-bit multiply.)
-        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(sh) : "s"(b), "v"(lane));
-        const uint32_t e0 = __builtin_amdgcn_alignbit(d1, d0, sh);
-        const uint32_t mask = (1u << b) - 1u;
-        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(x) : "v"(e0), "s"(mask), "v"(vbase));
-        return __uint_as_float(x);
-    };
     uint32_t n_colour = 0;  // chunks of this wave whose colours were loaded (frame statistics)
     // (Skipping the per-point conservative test below for chunks that have been through the lane test -- inside a stretch
     // of the cloud that lies in the frustum nearly every point passes it -- was measured: 135-142 us against 122-124.  A
@@ -1404,18 +1392,19 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
             const uint32_t cq = c_use < nchunks ? (c_use | 0x80000000u) : nchunks - 1u;
             c_use = next_chunk(c_use);
             const uint32_t wx = ww & 63u, wy = (ww >> 6) & 63u, wz = (ww >> 12) & 63u;
-            // the lane's two dwords of each A stream
+            if (!(cq >> 31)) continue;  // (wave-uniform) past the wave's last chunk
+            // the lane's two dwords of each A stream (bit b l: dword (b l) >> 5, shift (b l) & 31 -- one product for both)
             ChunkRawA raw;
+            uint32_t px, py, pz;
+            asm("v_mul_u32_u24 %0, %1, %2" : "=v"(px) : "s"(wx), "v"(lane));
+            asm("v_mul_u32_u24 %0, %1, %2" : "=v"(py) : "s"(wy), "v"(lane));
+            asm("v_mul_u32_u24 %0, %1, %2" : "=v"(pz) : "s"(wz), "v"(lane));
             {
-                const uint32_t ix = (wx * (uint32_t)lane) >> 5, iy = 2u * wx + ((wy * (uint32_t)lane) >> 5);
-                const uint32_t iz = 2u * (wx + wy) + ((wz * (uint32_t)lane) >> 5);
+                const uint32_t ix = px >> 5, iy = 2u * wx + (py >> 5), iz = 2u * (wx + wy) + (pz >> 5);
                 raw.a[0].d[0] = slot[ix], raw.a[0].d[1] = slot[ix + 1];
                 raw.a[1].d[0] = slot[iy], raw.a[1].d[1] = slot[iy + 1];
                 raw.a[2].d[0] = slot[iz], raw.a[2].d[1] = slot[iz + 1];
             }
-            uint32_t i_c = (cq & 0x7FFFFFFFu) * 64u + (uint32_t)lane;
-            const bool live_c = (cq >> 31) != 0u && i_c < n4;
-            i_c = i_c < n4 ? i_c : n4 - 1u;  // (masked lanes: any valid address for the colour load)
             Rows r;
             float4 X, Y, Z;
 #ifdef RTR_EXPERIMENT
@@ -1428,12 +1417,22 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
             bool cand = true;
             const uint32_t sp_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)g1.z);
             if (lane_test && !(ww & kPackWideFlag) && sp_c < 0x7F000000u) {
-                const float x0 = first_value(raw.a[0].d[0], raw.a[0].d[1], wx, bx);
-                const float y0 = first_value(raw.a[1].d[0], raw.a[1].d[1], wy, by);
-                const float z0 = first_value(raw.a[2].d[0], raw.a[2].d[1], wz, bz);
-                cand = lane_maybe(x0, y0, z0, __uint_as_float(sp_c), live_c);
+                // (b = 0: the mask is empty, the value is the base.  Lanes past the cloud's end hold copies of its last
+                // quad -- k_pack_write -- so the test needs no mask of its own: the long path has one)
+                auto value0 = [&](uint32_t d0, uint32_t d1, uint32_t prod, uint32_t b, uint32_t base) -> float {
+                    uint32_t x;
+                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(x) : "v"(__builtin_amdgcn_alignbit(d1, d0, prod)), "s"((1u << b) - 1u), "v"(base));
+                    return __uint_as_float(x);
+                };
+                const float x0 = value0(raw.a[0].d[0], raw.a[0].d[1], px, wx, bx);
+                const float y0 = value0(raw.a[1].d[0], raw.a[1].d[1], py, wy, by);
+                const float z0 = value0(raw.a[2].d[0], raw.a[2].d[1], pz, wz, bz);
+                cand = lane_maybe(x0, y0, z0, __uint_as_float(sp_c), true);
             }
             if (!cand) continue;
+            uint32_t i_c = (cq & 0x7FFFFFFFu) * 64u + (uint32_t)lane;
+            const bool live_c = i_c < n4;
+            i_c = live_c ? i_c : n4 - 1u;  // (masked lanes: any valid address for the colour load)
             {
                 const uint32_t sbx = (uint32_t)__builtin_amdgcn_readfirstlane((int)bx), sby = (uint32_t)__builtin_amdgcn_readfirstlane((int)by);
                 const uint32_t sbz = (uint32_t)__builtin_amdgcn_readfirstlane((int)bz);
