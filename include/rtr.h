@@ -118,9 +118,11 @@ int rtr_get_params(const rtr_ctx *ctx, rtr_params *p);
  *          the exact arithmetic before it can reach a pixel; 0 = every point of every chunk, as before.
  *  "pack": the tile-binned point kernel reads the coordinates from a LOSSLESS packed form, built once after
  *          every upload / generation / sort (and at once for the resident cloud when the option is set): per
- *          256-point chunk and axis the fp32 bit patterns are base + delta with 0..4 delta bytes, i.e. 6-9
- *          B/pt instead of 12 for spatially ordered clouds (neighbours share sign, exponent and leading
- *          mantissa bits); any bit pattern round-trips (NaNs, -0, mixed signs take 4 bytes).  1 (default):
+ *          256-point chunk and axis the fp32 bit patterns are a common prefix + the 0..25 (or 32) bits below it
+ *          of every value, i.e. 5-9 B/pt instead of 12 for spatially ordered clouds (neighbours share sign,
+ *          exponent and leading mantissa bits), in two bit streams per axis -- every lane's first value, and its
+ *          other three -- so that the chunks the point kernel rejects on one point per lane are read through a
+ *          quarter of their bytes; any bit pattern round-trips (NaNs, -0, mixed signs take 32 bits).  1 (default):
  *          used when it saves at least 1/8 of the stream; 0: never; 2: always, and the packed form is
  *          decoded and compared with the SoA arrays once (an error if a single point differs).  rtr_get_option:
  *          "packed" (1: in use), "packed_millibytes_per_point" (coordinate stream incl. headers, 12000 = raw).
