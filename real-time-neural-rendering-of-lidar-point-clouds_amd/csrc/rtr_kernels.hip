@@ -1352,14 +1352,14 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
         auto req_hdr = [&](uint32_t q, uint32_t c) {  // (c: position q's chunk; past the cloud's end: its last chunk, masked later)
             const uint32_t cc = c < nchunks ? c : nchunks - 1u;
             const uint32_t voff = 32u * cc + lane16, lds = rhdr_lds + 32u * (q & (uint32_t)kRingH);
-            if (lane < 2) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(pk_hdr), "s"(lds) : "memory");
+            if (lane < 2) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(pk_hdr), "s"(lds) : "memory", "m0");
         };
         auto req_data = [&](uint32_t q) {  // position q's header has landed
             const lds_u32 *const hs = (const lds_u32 *)(uintptr_t)(rhdr_lds + 32u * (q & (uint32_t)kRingH));
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)hs[4]), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hs[5]);
             const uint8_t *src = reinterpret_cast<const uint8_t *>(pk_planes) + (((((uint64_t)hi) << 32) | (uint64_t)lo) << 3);
             const uint32_t lds = ring_lds + 4u * (uint32_t)kSlotDw * (q & (uint32_t)kRing);
-            if (lane < 48) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane16), "s"(src), "s"(lds) : "memory");
+            if (lane < 48) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane16), "s"(src), "s"(lds) : "memory", "m0");
         };
         // (prologue: two drains, ~2 us once per launch, so that every wait below may count two requests per iteration)
         uint32_t c_req = c_first;
