@@ -1296,8 +1296,8 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
     };
 
     if (!CULL && PACKED) {
-        // the same pipeline as below on the packed form, one stage deeper: header of chunk q + 2, planes of chunk
-        // q + 1 (<= 12 dwords per lane, usually 6-9) and the arithmetic of chunk q are in flight together
+        // HISTORY of this loop (rounds 2-4, one bit stream per axis, a register pipeline like the fp32 loop's below, one
+        // stage deeper: header of chunk q + 2, planes of chunk q + 1 and the arithmetic of chunk q in flight together).
         // (Two chunks of planes in flight per wave -- buffers A / B, loop unrolled by two -- lift the loads alone from 95
         // to 87 us (one chunk per wave and memory round trip is 4096 x 1.3 KB / ~1 us = 5.4 TB/s), but the whole kernel
         // gets 5 us slower: 14 more spilled scalar registers and their v_readlane traffic.  Measured in rounds 2 and 3.
@@ -1313,19 +1313,19 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
         // q + 2 requested as soon as chunk q has been read out of its slot: two chunks in flight per wave, no register holds
         // data in flight; bit-exact at the first attempt): 121.4-121.6 us against 120.2-120.8, 1e7 points 22.1-22.6 against
         // 22.7-22.9 -- twice the bytes in flight buy nothing: the stream part of the launch already runs at the rate
-        // the chip sustains, what is left is the chain of the chunks inside the frustum.)
-        // No branch depends on whether the wave still has a chunk: past its last one it re-reads the cloud's
-        // last chunk with every lane masked (at most two wasted iterations per wave), so the compiler sees
-        // straight-line code and waits for the chunk's three loads exactly once, where they are decoded.
-        // The light path reads the chunk's A streams only (every lane's FIRST value: a quarter of the chunk); the B streams
-        // are requested when the lane test leaves a candidate lane.
+        // the chip sustains, what is left is the chain of the chunks inside the frustum.)  All of that held while a chunk was
+        // 1.3 KB; the form below reads a quarter of it.
+        //
+        // NOW: the light path reads the chunk's A streams only (every lane's FIRST value: a quarter of the chunk); the B
+        // streams are requested when the lane test leaves a candidate lane.  Past its last chunk a wave re-requests the
+        // cloud's last chunk and skips the position.
         //
         // THE RING.  With a quarter of the bytes per chunk the loop is no longer near HBM's rate but bound by its own
         // chain -- one chunk in flight per wave, one memory round trip per iteration (T1 112-117 us against 119-122: 60 %
         // fewer bytes bought 6 %).  So the A streams of the next kRing chunks are in flight at once, and in no register:
         // a chunk's A streams are one contiguous piece of at most 768 bytes, which ONE global_load_lds_dwordx4 (16 bytes
-        // per lane, 1 KB per wave) lands in an LDS slot of the wave; the headers travel the same way (two lanes' worth,
-        // 32 bytes), two chunks further ahead, because a chunk's data request needs the offset its header holds -- so
+        // per lane, 48 lanes) lands in an LDS slot of the wave; the headers travel the same way (two lanes' worth,
+        // 32 bytes), kLead chunks further ahead, because a chunk's data request needs the offset its header holds -- so
         // no header lives in scalar registers any more, and no scalar load's latency sits on the LDS reads' counter.
         // Iteration q: request header q + kRing + kLead; header q + kRing has landed (vmcnt(2 kLead): the requests return in
         // order, two per iteration) -> request its data into the slot chunk q - 1 has left; data q has landed (vmcnt(2 kRing))
