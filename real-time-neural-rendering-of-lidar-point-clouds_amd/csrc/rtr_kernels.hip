@@ -1361,16 +1361,18 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
             const uint32_t lds = ring_lds + 4u * (uint32_t)kSlotDw * (q & (uint32_t)kRing);
             if (lane < 48) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane16), "s"(src), "s"(lds) : "memory", "m0");
         };
-        // (prologue: two drains, ~2 us once per launch, so that every wait below may count two requests per iteration)
+        // (prologue: one drain, ~1.5 us once per launch, so that every wait below may count two requests per iteration)
         uint32_t c_req = c_first;
 #pragma unroll
         for (int k = 0; k < kRingH; ++k) {
             req_hdr((uint32_t)k, (uint32_t)k < R ? c_req : nchunks);
             c_req = next_chunk(c_req);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int k = 0; k < kRing; ++k) req_data((uint32_t)k);
+        for (int k = 0; k < kRing; ++k) {
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kRingH - 1) : "memory");  // header k: kRingH - 1 requests behind it
+            req_data((uint32_t)k);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef RTR_EXPERIMENT
         uint32_t xp_sink = 0;
