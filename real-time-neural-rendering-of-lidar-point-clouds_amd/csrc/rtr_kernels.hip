@@ -1440,7 +1440,14 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
                 const uint32_t sbz = (uint32_t)__builtin_amdgcn_readfirstlane((int)bz);
                 const uint4 hc0 = make_uint4(sbx, sby, sbz, ww);
                 const uint4 hc1 = make_uint4((uint32_t)__builtin_amdgcn_readfirstlane((int)g1.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)g1.y), 0u, 0u);
-                const ChunkRaw raw_b = load_chunk_b(pk_planes_b, hc0, hc1, lane);
+                ChunkRaw raw_b;
+#ifdef RTR_EXPERIMENT
+                if (RTR_XP(1024)) {  // (what the B streams' round trip costs: the A data in their place, wrong frames)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) raw_b.a[a].d[0] = raw.a[a].d[0], raw_b.a[a].d[1] = raw.a[a].d[1], raw_b.a[a].d[2] = raw.a[a].d[0], raw_b.a[a].d[3] = raw.a[a].d[1];
+                } else
+#endif
+                raw_b = load_chunk_b(pk_planes_b, hc0, hc1, lane);
                 unpack_chunk(raw, raw_b, ww, sbx, sby, sbz, X, Y, Z, lane);
                 project_rows(X, Y, Z, r);
             }
