@@ -1879,6 +1879,7 @@ extern "C" int rtr_debug_stamps(rtr_ctx *c, unsigned long long out[64]) {  // ti
     if (!c || !out || !c->F().store.meta) return RTR_ERR_INVALID;
     DevGuard g(c->device);
     HIP_TRY(c, hipMemcpyAsync(out, rtr::ts_dbg(c->F().store), 64 * 8, hipMemcpyDeviceToHost, c->stream));
+    rtr::read_filter_stamps(c->stream, out + 24);  // (words 24..39: two workgroups of k_filter4; the second tile workgroup's stamps give way)
     HIP_TRY(c, hipMemsetAsync(rtr::ts_dbg(c->F().store) + 40, 0, 8 * 8, c->stream));
     HIP_TRY(c, hipMemsetAsync(rtr::ts_dbg(c->F().store) + 56, 0, 8 * 8, c->stream));  // (the per-wave maxima / sums of T1)
     HIP_TRY(c, sync_streams(c));

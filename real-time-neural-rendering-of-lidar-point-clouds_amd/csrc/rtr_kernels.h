@@ -228,6 +228,9 @@ __host__ __device__ inline const StoreConsts *ts_consts(const TileStore &S) {
     return reinterpret_cast<const StoreConsts *>(ts_hdr(S) + kHdrConsts);
 }
 
+#ifdef RTR_EXPERIMENT
+void read_filter_stamps(hipStream_t s, unsigned long long *out16);
+#endif
 void launch_clear(hipStream_t s, uint32_t *depth, uint32_t *acc, size_t npix);
 // mode 0: the reference's structure (two full streams, global atomics)
 void launch_min_depth(hipStream_t s, const Cloud &c, const Proj &P, int W, int H, uint32_t *depth);

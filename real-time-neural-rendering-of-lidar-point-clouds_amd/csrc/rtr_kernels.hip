@@ -3333,6 +3333,15 @@ __device__ __forceinline__ void up_level(float *hi, int ox, int oy, int hw, int 
     }
 }
 
+#ifdef RTR_EXPERIMENT
+__device__ unsigned long long g_fstamp[2][8];  // time stamps inside two workgroups of k_filter4 (tools/stamps.py)
+#define RTR_FSTAMP(k) do { if (threadIdx.x == 0 && (blockIdx.x == 5 || blockIdx.x == 1900)) g_fstamp[blockIdx.x == 5 ? 0 : 1][k] = wall_clock64(); } while (0)
+void read_filter_stamps(hipStream_t s, unsigned long long *out16) {
+    (void)hipMemcpyFromSymbolAsync(out16, HIP_SYMBOL(g_fstamp), sizeof g_fstamp, 0, hipMemcpyDeviceToHost, s);
+}
+#else
+#define RTR_FSTAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(kBlock) void k_filter4(const float *__restrict__ g1, const float *__restrict__ g2,
                                                     const float *__restrict__ g3, const float *__restrict__ g4,
                                                     int h4, float *__restrict__ depth, uint8_t *__restrict__ img,
@@ -3346,6 +3355,7 @@ __global__ __launch_bounds__(kBlock) void k_filter4(const float *__restrict__ g1
     __shared__ uint32_t s_mm[8];
     __shared__ uint16_t s_lut[256];  // colour byte -> fp16 bits: one IEEE division per thread instead of twelve
     static_assert(kBlock == 256, "one table entry per thread");
+    RTR_FSTAMP(0);
     s_lut[threadIdx.x] = (uint16_t)colour_half(threadIdx.x);
     const int X0 = (blockIdx.x % blocks_x) * kFuseW, Y0 = (blockIdx.x / blocks_x) * kFuseH;
     const int t = threadIdx.x, x = X0 + 4 * (t & 15), y = Y0 + (t >> 4);
@@ -3379,6 +3389,7 @@ __global__ __launch_bounds__(kBlock) void k_filter4(const float *__restrict__ g1
         s_mm[t >> 6] = fa;
         s_mm[4 + (t >> 6)] = fb;
     }
+    RTR_FSTAMP(1);  // frame loads requested, partials folded
     const int w1 = W >> 1, w2 = W >> 2, w3 = W >> 3, w4 = W >> 4, h3 = 2 * h4, h2 = 4 * h4, h1 = 8 * h4;
     const int x1 = (X0 >> 1) - 1, y1 = (Y0 >> 1) - 1, x2 = (X0 >> 2) - 2, y2 = (Y0 >> 2) - 2;
     const int x3 = (X0 >> 3) - 2, y3 = (Y0 >> 3) - 2, x4 = (X0 >> 4) - 2, y4 = (Y0 >> 4) - 2;
@@ -3387,12 +3398,14 @@ __global__ __launch_bounds__(kBlock) void k_filter4(const float *__restrict__ g1
     stage_level<kF3x, kF3y>(s3, x3, y3, g3, w3, h3);
     stage_level<kF4x, kF4y>(s4, x4, y4, g4, w4, h4);
     __syncthreads();
+    RTR_FSTAMP(2);  // levels staged
     up_level<kF3x, kF3y>(s3, x3, y3, w3, h3, LdsLevel{s4, x4, y4, kF4x, w4, h4}, strength, thr);
     __syncthreads();
     up_level<kF2x, kF2y>(s2, x2, y2, w2, h2, LdsLevel{s3, x3, y3, kF3x, w3, h3}, strength, thr);
     __syncthreads();
     up_level<kF1x, kF1y>(s1, x1, y1, w1, h1, LdsLevel{s2, x2, y2, kF2x, w2, h2}, strength, thr);
     __syncthreads();
+    RTR_FSTAMP(3);  // three up steps
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         fa = s_mm[k] < fa ? s_mm[k] : fa;
@@ -3406,6 +3419,7 @@ __global__ __launch_bounds__(kBlock) void k_filter4(const float *__restrict__ g1
     if (!inb) return;
     final_quad(LdsLevel{s1, x1, y1, kF1x, w1, h1}, d4, iw0, iw1, iw2, depth, img, mask, tensor, mn, range,
                x, y, idx, npix, y < 2 * h1, strength, thr, s_lut);
+    RTR_FSTAMP(4);  // final step issued (its stores are on their way)
 }
 
 // A14 applyDepthFilter (project_cloud.cu:331-392)
