@@ -834,6 +834,10 @@ def main():
             # clear / resolve work, ~50 B/px of prefilter) ...
             "frame_required_bytes": required,
             "frame_required_bytes_frac": required / step_s / 1e9 / HBM_PEAK_GBS,
+            "frame_required_bytes_note": "SURVEY.md 8d's ALGORITHMIC bytes (12 B per point + 39 B per pixel, + the prefilter's) over "
+                                         "the frame's time and 8 TB/s: a comparison with an ideal fp32 stream, not a roofline "
+                                         "fraction -- above 1 when the frame reads fewer bytes than that (lossless packed "
+                                         "coordinates of which the lane test reads a quarter); roofline.frac is the measured one",
             # ... the same with the coordinate stream at its RESIDENT size (packed clouds: what HBM really delivers)
             "frame_resident_bytes": required - (12.0 - stream_bpp) * n_local,
             "frame_resident_bytes_frac": (required - (12.0 - stream_bpp) * n_local) / step_s / 1e9 / HBM_PEAK_GBS,
