@@ -3371,13 +3371,32 @@ __global__ __launch_bounds__(kBlock) void k_filter4(const float *__restrict__ g1
         const uint32_t *ip = reinterpret_cast<const uint32_t *>(src + idx * 3);
         iw0 = ip[0]; iw1 = ip[1]; iw2 = ip[2];
     }
-    // A12: every workgroup folds the per-tile min / max partials itself (a few KB out of L2, in
-    // the shadow of the loads above) rather than waiting for a fold launch
+    const int w1 = W >> 1, w2 = W >> 2, w3 = W >> 3, w4 = W >> 4, h3 = 2 * h4, h2 = 4 * h4, h1 = 8 * h4;
+    const int x1 = (X0 >> 1) - 1, y1 = (Y0 >> 1) - 1, x2 = (X0 >> 2) - 2, y2 = (Y0 >> 2) - 2;
+    const int x3 = (X0 >> 3) - 2, y3 = (Y0 >> 3) - 2, x4 = (X0 >> 4) - 2, y4 = (Y0 >> 4) - 2;
+    stage_level<kF1x, kF1y>(s1, x1, y1, g1, w1, h1);
+    stage_level<kF2x, kF2y>(s2, x2, y2, g2, w2, h2);
+    stage_level<kF3x, kF3y>(s3, x3, y3, g3, w3, h3);
+    stage_level<kF4x, kF4y>(s4, x4, y4, g4, w4, h4);
+    RTR_FSTAMP(1);  // frame loads requested, levels staged
+    // A12: every workgroup folds the per-tile min / max partials itself (16 KB out of L2) rather than waiting for a fold
+    // launch -- behind the level staging, so that its wait is not also the wait for the frame-sized loads above
     uint32_t fa = 0xFFFFFFFFu, fb = 0u;
-    for (int k = t; k < nparts; k += kBlock) {
-        const uint32_t pa = part_min[k], pb = part_max[k];
-        fa = pa < fa ? pa : fa;
-        fb = pb > fb ? pb : fb;
+    {   // (16 bytes per load: 2040 workgroups read these 16 KB at the same moment)
+        const int n4p = nparts >> 2;
+        const uint4 *const pm4 = reinterpret_cast<const uint4 *>(part_min), *const px4 = reinterpret_cast<const uint4 *>(part_max);
+        for (int k = t; k < n4p; k += kBlock) {
+            const uint4 a = pm4[k], b = px4[k];
+            const uint32_t a2 = a.x < a.y ? a.x : a.y, a3 = a.z < a.w ? a.z : a.w, b2 = b.x > b.y ? b.x : b.y, b3 = b.z > b.w ? b.z : b.w;
+            const uint32_t pa = a2 < a3 ? a2 : a3, pb = b2 > b3 ? b2 : b3;
+            fa = pa < fa ? pa : fa;
+            fb = pb > fb ? pb : fb;
+        }
+        for (int k = 4 * n4p + t; k < nparts; k += kBlock) {
+            const uint32_t pa = part_min[k], pb = part_max[k];
+            fa = pa < fa ? pa : fa;
+            fb = pb > fb ? pb : fb;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -3389,16 +3408,8 @@ __global__ __launch_bounds__(kBlock) void k_filter4(const float *__restrict__ g1
         s_mm[t >> 6] = fa;
         s_mm[4 + (t >> 6)] = fb;
     }
-    RTR_FSTAMP(1);  // frame loads requested, partials folded
-    const int w1 = W >> 1, w2 = W >> 2, w3 = W >> 3, w4 = W >> 4, h3 = 2 * h4, h2 = 4 * h4, h1 = 8 * h4;
-    const int x1 = (X0 >> 1) - 1, y1 = (Y0 >> 1) - 1, x2 = (X0 >> 2) - 2, y2 = (Y0 >> 2) - 2;
-    const int x3 = (X0 >> 3) - 2, y3 = (Y0 >> 3) - 2, x4 = (X0 >> 4) - 2, y4 = (Y0 >> 4) - 2;
-    stage_level<kF1x, kF1y>(s1, x1, y1, g1, w1, h1);
-    stage_level<kF2x, kF2y>(s2, x2, y2, g2, w2, h2);
-    stage_level<kF3x, kF3y>(s3, x3, y3, g3, w3, h3);
-    stage_level<kF4x, kF4y>(s4, x4, y4, g4, w4, h4);
     __syncthreads();
-    RTR_FSTAMP(2);  // levels staged
+    RTR_FSTAMP(2);  // partials folded
     up_level<kF3x, kF3y>(s3, x3, y3, w3, h3, LdsLevel{s4, x4, y4, kF4x, w4, h4}, strength, thr);
     __syncthreads();
     up_level<kF2x, kF2y>(s2, x2, y2, w2, h2, LdsLevel{s3, x3, y3, kF3x, w3, h3}, strength, thr);

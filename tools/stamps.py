@@ -28,7 +28,7 @@ for k in range(8, 12):
                int(u[62]) / int(u[60]), int(u[61])))
         print("   one wave in eight by its own duration (<60, 60-80, ... 180-200, >=200 us):", [int(v) for v in u[40:48]])
     for name, b in (("wg5", 24), ("wg1900", 32)):  # k_filter4 (the copy of these words is asynchronous: read after the sync below)
-        print("  F2 %s: LUT + loads requested + partials folded %s, levels staged + barrier %s, three up steps %s, final step %s | total %s" %
+        print("  F2 %s: LUT + frame loads requested + levels staged %s, partials folded + barrier %s, three up steps %s, final step %s | total %s" %
               (name, us(b, b + 1), us(b + 1, b + 2), us(b + 2, b + 3), us(b + 3, b + 4), us(b, b + 4)))
     for name, b in (("wg5", 8),):
         print("     %s detail: loads issued->first arrives %s, ->all %s, min-merge+atomics %s | acc body %s, barrier %s, overflow check+barrier %s" %
