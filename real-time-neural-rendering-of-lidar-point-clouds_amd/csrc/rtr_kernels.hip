@@ -1076,7 +1076,13 @@ __global__ __launch_bounds__(kBlock, (PACKED && !CULL) ? RTR_T1_WAVES : 4) void 
     // claims on the dozen stream counters of a distant overview -- and 16 groups that sit in different parts
     // of the cloud, i.e. in different tiles, spread them: 1.45 -> 0.87 ms for 1e8 points inside 100 x 40
     // pixels, against +10 us on an ordinary view, which therefore keeps the single dense streaming front.
-    const uint32_t auto_groups = ts_hdr(S)[kHdrEntries] > n4 ? 16u : 1u;
+    // The packed kernel (round 4: the light path reads a quarter of each chunk through an LDS ring and is bound by the
+    // instructions it issues, no longer by the stream) takes FIVE groups by default when a wave has at least 16 rounds: the
+    // five workgroups of a CU then sit in five stretches of the cloud, so a stretch inside the frustum puts one of a
+    // SIMD's five waves on the long path at a time instead of all of them -- 104.1 -> 99.5-100.8 us on C3; equal on the
+    // sorted uniform_box and on BASELINE C2's 1e7 points (fewer rounds: one group); the fp32 stream, which IS at HBM's
+    // rate, keeps its single front (five groups: 227 us against 201-205).
+    const uint32_t auto_groups = ts_hdr(S)[kHdrEntries] > n4 ? 16u : ((PACKED && !CULL && GROUPS && R >= 16u) ? 5u : 1u);
     const uint32_t G = cblock < 1u ? auto_groups : (cblock > gridDim.x ? gridDim.x : cblock);
     const uint32_t phase = (uint32_t)((uint64_t)((blockIdx.x * G) / gridDim.x) * R / G);
     auto chunk_of = [&](uint32_t q) -> uint32_t {  // q-th chunk of this wave, q < R (>= nchunks: none)
